@@ -1,0 +1,322 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/salp_vec.h) against the CPU oracle
+on the same seeded inputs.  Run on the MI355X box with `pytest -m gpu`.
+
+Tolerances (north_star: "within 1e-5 fp32"):
+  * terminated / truncated / info integers: identical;
+  * observation: max |diff| <= 1e-5 (columns holding an angle/pi are compared on the circle,
+    i.e. modulo 2, because -1 and +1 are the same heading — snake:403-407 wraps to [-pi, pi]);
+  * reward: |diff| <= 1e-5 * max(1, |reward|);
+  * fp64 state snapshot: |diff| <= 1e-9 (only device sin/cos and d^2-vs-sqrt predicates differ).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import underwater_swimmer_rl_amd as pkg
+from underwater_swimmer_rl_amd import _capi
+from underwater_swimmer_rl_amd._capi import SalpLib
+
+pytestmark = pytest.mark.gpu
+
+OBS_TOL = 1e-5
+REW_TOL = 1e-5
+STATE_TOL = 1e-9
+
+
+def angle_cols(cfg):
+    return [4] + [10 + 4 * s + 3 for s in range(cfg.max_observed_food)]
+
+
+def obs_diff(cfg, a, b):
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    for c in angle_cols(cfg):
+        d[..., c] = np.minimum(d[..., c], 2.0 - d[..., c])
+    return d
+
+
+def run_device(cfg, n, act=None, horizon=None, seed=0, base=0, want_final=False, dev=None):
+    own = dev is None
+    if own:
+        dev = SalpLib(cfg, n, device_id=0, seed=seed, env_index_base=base)
+    H = act.shape[0] if act is not None else horizon
+    obs = np.empty((H, n, cfg.obs_dim), np.float32)
+    rew = np.empty((H, n), np.float32)
+    term = np.empty((H, n), np.uint8)
+    trunc = np.empty((H, n), np.uint8)
+    fin = np.full((H, n, cfg.obs_dim), np.nan, np.float32) if want_final else None
+    aout = np.empty((H, n, cfg.act_dim), np.float32) if act is None else None
+    dev.rollout(act, H, obs, rew, term, trunc, fin, aout, 0)
+    out = dict(obs=obs, reward=rew, terminated=term, truncated=trunc, final_obs=fin, actions=aout)
+    return (out, dev) if not own else (out, dev)
+
+
+def get_state(dev, cfg):
+    f64 = np.empty((_capi.F_FOOD0 + 2 * cfg.num_food_items, dev.n_envs), np.float64)
+    i32 = np.empty((_capi.I_COUNT, dev.n_envs), np.int32)
+    dev.get_state(f64, i32, 0)
+    return f64, i32
+
+
+def assert_parity(cfg, got, ref, label=""):
+    assert np.array_equal(got["terminated"], ref["terminated"]), f"{label}: terminated flags differ"
+    assert np.array_equal(got["truncated"], ref["truncated"]), f"{label}: truncated flags differ"
+    d = obs_diff(cfg, got["obs"], ref["obs"])
+    assert d.max() <= OBS_TOL, f"{label}: obs diff {d.max()} at {np.unravel_index(d.argmax(), d.shape)}"
+    rd = np.abs(got["reward"].astype(np.float64) - ref["reward64"]) / np.maximum(1.0, np.abs(ref["reward64"]))
+    assert rd.max() <= REW_TOL, f"{label}: reward diff {rd.max()}"
+    return float(d.max()), float(rd.max())
+
+
+def assert_state_parity(cfg, dev, orc, label=""):
+    f_d, i_d = get_state(dev, cfg)
+    f_o, i_o = orc.get_state()
+    assert np.array_equal(i_d, i_o), f"{label}: integer state differs in rows {np.unique(np.nonzero(i_d != i_o)[0])}"
+    both_nan = np.isnan(f_d) & np.isnan(f_o)
+    assert np.array_equal(np.isnan(f_d), np.isnan(f_o)), f"{label}: food None-pattern differs"
+    d = np.where(both_nan, 0.0, np.abs(f_d - f_o))
+    assert d.max() <= STATE_TOL, f"{label}: fp64 state diff {d.max()} in row {np.unravel_index(d.argmax(), d.shape)}"
+
+
+CASES = {
+    "single_food": dict(preset="single_food"),
+    "long_horizon": dict(preset="single_food_long_horizon"),
+    "sac_gail_F12": dict(preset="sac_gail"),
+    "free_breathing": dict(preset="single_food", forced_breathing=False),
+    "no_respawn_F3": dict(preset="sac_gail", num_food_items=3, respawn_food=False),
+    "random_count_F5": dict(preset="sac_gail", num_food_items=5, random_food_count=True),
+    "K2_generic": dict(preset="sac_gail", num_food_items=6, max_observed_food=2, proximity_reward_weight=2.0),
+    "K0_no_food_obs": dict(preset="single_food", max_observed_food=0),
+    "F0_empty": dict(preset="single_food", num_food_items=0),
+    "short_timeout": dict(preset="single_food", max_steps_without_food=40),
+}
+
+
+def make_cfg(spec):
+    spec = dict(spec)
+    return pkg.load_env_config(spec.pop("preset"), **spec)
+
+
+def make_actions(cfg, H, n, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    act = rng.uniform(-scale, scale, size=(H, n, cfg.act_dim)).astype(np.float32)
+    if not cfg.forced_breathing:  # inhale control in [0,1], held for random stretches
+        hold = rng.uniform(0, 1, size=(H // 16 + 1, n)).repeat(16, axis=0)[:H]
+        act[..., 0] = hold.astype(np.float32)
+    return act
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_rollout_parity(name):
+    cfg = make_cfg(CASES[name])
+    n, H, seed = 2048, 384, 11
+    act = make_actions(cfg, H, n, seed=3)
+    got, dev = run_device(cfg, n, act, seed=seed, want_final=True)
+    orc = ol.OracleVec(cfg, n, seed=seed)
+    ref = orc.rollout(act, want_final=True)
+    dmax, rmax = assert_parity(cfg, got, ref, name)
+    # terminal observations are delivered for finished envs only
+    done = (ref["terminated"] | ref["truncated"]).astype(bool)
+    assert np.array_equal(np.isnan(got["final_obs"][..., 0]), ~done)
+    if done.any():
+        assert obs_diff(cfg, got["final_obs"][done], ref["final_obs"][done]).max() <= OBS_TOL
+    assert_state_parity(cfg, dev, orc, name)
+    st = dev.stats()
+    assert st["env_steps"] == n * H
+    assert st["episodes"] == int(done.sum())
+    assert st["terminated"] == int(ref["terminated"].sum()) and st["truncated"] == int(ref["truncated"].sum())
+    print(f"{name}: max obs diff {dmax:.3g}, max rel reward diff {rmax:.3g}, episodes {st['episodes']}")
+    dev.close()
+
+
+def test_config2_4096x256_single_food():
+    """BASELINE.json configs[1]: N_envs=4096 single_food, 256-step rollout, fp32 diff <= 1e-5."""
+    cfg = pkg.load_env_config("single_food")
+    n, H = 4096, 256
+    act = make_actions(cfg, H, n, seed=0)
+    got, dev = run_device(cfg, n, act, seed=0)
+    ref = ol.OracleVec(cfg, n, seed=0).rollout(act)
+    dmax, rmax = assert_parity(cfg, got, ref, "config2")
+    print(f"config2: max obs diff {dmax:.3g}, max rel reward diff {rmax:.3g}")
+    dev.close()
+
+
+def test_long_rollout_wall_and_food_events():
+    """2000 steps: many wall terminations, food captures + respawns, the rounding-escape case."""
+    cfg = pkg.load_env_config("single_food_long_horizon")
+    n, H = 512, 2000
+    act = make_actions(cfg, H, n, seed=9)
+    got, dev = run_device(cfg, n, act, seed=5)
+    orc = ol.OracleVec(cfg, n, seed=5)
+    ref = orc.rollout(act)
+    assert ref["terminated"].sum() > 100
+    assert_parity(cfg, got, ref, "long")
+    assert_state_parity(cfg, dev, orc, "long")
+    dev.close()
+
+
+def test_step_equals_rollout_and_info():
+    cfg = pkg.load_env_config("sac_gail")
+    n, H, seed = 777, 300, 21   # ragged: not a multiple of 64
+    act = make_actions(cfg, H, n, seed=4)
+    got, dev_r = run_device(cfg, n, act, seed=seed)
+    dev_s = SalpLib(cfg, n, device_id=0, seed=seed)
+    orc = ol.OracleVec(cfg, n, seed=seed)
+    ref = orc.rollout(act)
+    obs = np.empty((n, cfg.obs_dim), np.float32)
+    rew = np.empty(n, np.float32)
+    term = np.empty(n, np.uint8)
+    trunc = np.empty(n, np.uint8)
+    info = np.empty((n, 3), np.int32)
+    for t in range(H):
+        dev_s.step(act[t], obs, rew, term, trunc, None, info, 0)
+        assert np.array_equal(obs, got["obs"][t]) and np.array_equal(rew, got["reward"][t])
+        assert np.array_equal(term, got["terminated"][t]) and np.array_equal(trunc, got["truncated"][t])
+        assert np.array_equal(info, ref["info"][t]), f"info differs at step {t}"
+    dev_r.close()
+    dev_s.close()
+
+
+def test_reset_observation_and_mask():
+    cfg = pkg.load_env_config("sac_gail")
+    n, seed = 1000, 3
+    dev = SalpLib(cfg, n, device_id=0, seed=seed)
+    orc = ol.OracleVec(cfg, n, seed=seed)
+    obs = np.empty((n, cfg.obs_dim), np.float32)
+    dev.observe(obs, 0)
+    assert obs_diff(cfg, obs, orc.observe()).max() <= OBS_TOL
+    act = make_actions(cfg, 50, n, seed=1)
+    run_device(cfg, n, act, dev=dev)
+    orc.rollout(act)
+    mask = (np.arange(n) % 3 == 0).astype(np.uint8)
+    dev.reset(mask, obs, 0)
+    ref = orc.reset(mask)
+    assert obs_diff(cfg, obs, ref).max() <= OBS_TOL
+    assert_state_parity(cfg, dev, orc, "masked reset")
+    dev.close()
+
+
+def test_device_generated_actions_match_oracle_stream():
+    cfg = pkg.load_env_config("single_food")
+    n, H, seed = 640, 200, 99
+    got, dev = run_device(cfg, n, None, horizon=H, seed=seed)
+    orc = ol.OracleVec(cfg, n, seed=seed)
+    ref = orc.rollout(None, horizon=H)
+    assert np.array_equal(got["actions"], ref["actions"])
+    assert got["actions"].min() >= -1.0 and got["actions"].max() < 1.0
+    assert_parity(cfg, got, ref, "device actions")
+    # second launch continues the action stream at global step H
+    got2, _ = run_device(cfg, n, None, horizon=50, dev=dev)
+    ref2 = orc.rollout(None, horizon=50)
+    assert np.array_equal(got2["actions"], ref2["actions"])
+    assert_parity(cfg, got2, ref2, "device actions, 2nd launch")
+    dev.close()
+
+
+def test_set_state_injection_eval_style():
+    """eval/collect_navigation_data.py:76-89: overwrite pose, velocity, heading and the food."""
+    cfg = pkg.load_env_config("single_food", respawn_food=False, max_steps_without_food=3000)
+    n, seed = 256, 1
+    dev = SalpLib(cfg, n, device_id=0, seed=seed)
+    orc = ol.OracleVec(cfg, n, seed=seed)
+    f64, i32 = get_state(dev, cfg)
+    rng = np.random.default_rng(2)
+    f64[_capi.F_X] = 150.0
+    f64[_capi.F_Y] = 300.0
+    f64[_capi.F_VX] = 0.0
+    f64[_capi.F_VY] = 0.0
+    f64[_capi.F_THETA] = rng.uniform(-np.pi, np.pi, n)
+    f64[_capi.F_OMEGA] = 0.0
+    f64[_capi.F_FOOD0] = 650.0
+    f64[_capi.F_FOOD0 + 1] = 300.0
+    i32[_capi.I_STEPS_SINCE_FOOD] = 0
+    dev.set_state(f64, i32, 0)
+    fo, io_ = orc.get_state()
+    fo[:] = f64
+    fo[_capi.F_ELLIPSE_A] = 30.0
+    fo[_capi.F_ELLIPSE_B] = 30.0
+    orc.set_state(fo, i32)
+    obs = np.empty((n, cfg.obs_dim), np.float32)
+    dev.observe(obs, 0)
+    assert obs_diff(cfg, obs, orc.observe()).max() <= OBS_TOL
+    act = make_actions(cfg, 600, n, seed=8, scale=0.3)
+    got, _ = run_device(cfg, n, act, dev=dev)
+    ref = orc.rollout(act)
+    assert_parity(cfg, got, ref, "injected")
+    assert_state_parity(cfg, dev, orc, "injected")
+    dev.close()
+
+
+def test_out_of_range_and_nan_actions():
+    """Actions are not clipped by the reference (legacy:125-135); NaN ends up at +max nozzle."""
+    cfg = pkg.load_env_config("single_food")
+    n, H = 128, 120
+    act = make_actions(cfg, H, n, seed=6, scale=3.0)
+    act[5::17, 3::7, 0] = np.nan
+    got, dev = run_device(cfg, n, act, seed=2)
+    orc = ol.OracleVec(cfg, n, seed=2)
+    ref = orc.rollout(act)
+    assert np.array_equal(got["terminated"], ref["terminated"])
+    ok = ~np.isnan(ref["obs"]).any(axis=-1)
+    assert obs_diff(cfg, got["obs"][ok], ref["obs"][ok]).max() <= OBS_TOL
+    assert np.array_equal(np.isnan(got["obs"]), np.isnan(ref["obs"]))
+    dev.close()
+
+
+def test_sharding_is_trajectory_invariant():
+    """env i's trajectory depends on its GLOBAL index only (multi-GPU sharding by env index)."""
+    cfg = pkg.load_env_config("sac_gail")
+    n, H, seed = 512, 150, 17
+    act = make_actions(cfg, H, n, seed=12)
+    full, d0 = run_device(cfg, n, act, seed=seed)
+    lo, d1 = run_device(cfg, n // 2, np.ascontiguousarray(act[:, : n // 2]), seed=seed, base=0)
+    hi, d2 = run_device(cfg, n // 2, np.ascontiguousarray(act[:, n // 2:]), seed=seed, base=n // 2)
+    for k in ("obs", "reward", "terminated", "truncated"):
+        assert np.array_equal(full[k][:, : n // 2], lo[k]) and np.array_equal(full[k][:, n // 2:], hi[k]), k
+    for d in (d0, d1, d2):
+        d.close()
+
+
+def test_properties_full_size_262144():
+    """BASELINE.json configs[2] size, checked through size-independent properties: bounded
+    observations, breathing period 273 in forced mode, |nozzle| <= 1, positions inside the tank,
+    env-step accounting, and agreement with the oracle on a strided sample of 256 envs."""
+    cfg = pkg.load_env_config("single_food_long_horizon")
+    n, H, seed = 262144, 300, 0
+    dev = SalpLib(cfg, n, device_id=0, seed=seed)
+    obs = np.empty((H, n, cfg.obs_dim), np.float32)
+    term = np.empty((H, n), np.uint8)
+    aout = np.empty((H, n, 1), np.float32)
+    dev.rollout(None, H, obs, None, term, None, None, aout, 0)
+    assert np.isfinite(obs).all()
+    assert obs[..., 0].min() >= (50 + 24) / 800 - 1e-6 and obs[..., 0].max() <= (750 - 24) / 800 + 1e-6
+    assert obs[..., 1].min() >= (50 + 24) / 600 - 1e-6 and obs[..., 1].max() <= (550 - 24) / 600 + 1e-6
+    assert np.abs(obs[..., 9]).max() <= 1.0 + 1e-6
+    assert obs[..., 8].min() >= 0.0 and obs[..., 8].max() <= 1.0
+    assert np.abs(obs[..., 4]).max() <= 1.0 + 1e-6
+    alive = term[:284].sum(axis=0) == 0                     # envs that did not reset in the first cycle
+    assert alive.sum() > n // 2
+    assert np.array_equal(obs[0, alive, 6], obs[273, alive, 6])   # body size repeats with period 273
+    assert np.array_equal(obs[10, alive, 7], obs[283, alive, 7])
+    assert dev.stats()["env_steps"] == n * H
+    idx = np.arange(0, n, n // 256)[:256]
+    for j, i in enumerate(idx[:64]):
+        orc = ol.OracleVec(cfg, 1, seed=seed, env_index_base=int(i))
+        ref = orc.rollout(np.ascontiguousarray(aout[:, i:i + 1]))
+        assert np.array_equal(term[:, i], ref["terminated"][:, 0])
+        assert obs_diff(cfg, obs[:, i], ref["obs"][:, 0]).max() <= OBS_TOL
+    dev.close()
+
+
+def test_create_rejects_bad_arguments():
+    lib = _capi.load_library()
+    cfg = pkg.load_env_config("single_food")
+    with pytest.raises(_capi.SalpError):
+        SalpLib(cfg, 0)
+    with pytest.raises(_capi.SalpError):
+        SalpLib(cfg, 16, device_id=99)
+    c = cfg.to_c()
+    c.struct_size = 8
+    import ctypes
+    h = ctypes.c_void_p()
+    assert lib.salp_vec_create(ctypes.byref(c), 16, 0, 0, 0, ctypes.byref(h)) == -1
+    assert b"struct_size" in lib.salp_last_error()

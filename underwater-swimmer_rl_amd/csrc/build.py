@@ -1,0 +1,37 @@
+"""Builds libsalp_hip.so (gfx950) in-tree with hipcc.  `python build.py [--force]`."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "salp_vec.hip")
+DEPS = [SRC, os.path.join(HERE, "salp_device.h"),
+        os.path.join(HERE, "..", "..", "include", "salp_vec.h")]
+OUT = os.path.join(HERE, "libsalp_hip.so")
+# -ffp-contract=off: the fp64 state update must round exactly where the reference rounds
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.isfile(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    cmd = [hipcc()] + FLAGS + ["-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=HERE)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,508 @@
+// salp_device.h — device-side arithmetic of one SALP swimmer (one env per lane), gfx950.
+//
+// Restates, for the GPU, the per-step arithmetic of the reference's
+//   scripts/utilities/salp_robot.py  ("legacy", SalpRobotEnv.step and helpers, :119-352)
+//   src/salp/environments/salp_snake_env.py ("snake", SalpSnakeEnv.step and helpers, :157-428)
+//
+// Numerics contract:
+//   * everything that feeds back into the state (nozzle, breathing, thrust, drag/integration,
+//     wall bounce, food placement) is IEEE fp64 in the reference's operation order; this file is
+//     compiled with -ffp-contract=off so no multiply-add is fused unless written as fma().
+//     The only departures from the reference's fp64 bit pattern are the device sin/cos (<=2 ulp
+//     vs glibc) and squared-distance predicates (d^2 < t^2 instead of sqrt(d^2) < t).
+//   * quantities that only leave the simulator (observation, reward shaping term) are derived
+//     from that fp64 state and finished in fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace salp {
+
+// ---- packed breathing word: phase[1:0] | timer[9:2] | exhale_dur[17:10] | shape_hold[20:18]
+__host__ __device__ inline uint32_t pack_breath(int phase, int timer, int dur, int hold) {
+  return (uint32_t)(phase & 3) | ((uint32_t)(timer & 255) << 2) | ((uint32_t)(dur & 255) << 10) |
+         ((uint32_t)(hold & 7) << 18);
+}
+__host__ __device__ inline int bw_phase(uint32_t w) { return (int)(w & 3u); }
+__host__ __device__ inline int bw_timer(uint32_t w) { return (int)((w >> 2) & 255u); }
+__host__ __device__ inline int bw_dur(uint32_t w) { return (int)((w >> 10) & 255u); }
+__host__ __device__ inline int bw_hold(uint32_t w) { return (int)((w >> 18) & 7u); }
+
+// Constants derived on the host in fp64 exactly as the reference derives them.
+struct DevParams {
+  // geometry / legacy constants
+  double W, H, half_W, half_H;
+  double margin;            // tank_margin (50)
+  double wall_hi_x, wall_hi_y;  // width - margin, height - margin (snake:226,228)
+  double R;                 // base_radius
+  double a_rest, b_rest;    // R*1.3, R*0.8             (legacy:190-191)
+  double ab_full;           // R*1.1                    (legacy:209-210)
+  double da_inh, db_inh;    // (end - start) inhaling   (legacy:212-213)
+  double da_exh, db_exh;    // (end - start) exhaling   (legacy:245-246)
+  double max_nozzle, nozzle_rate, thrust_force, drag, ang_drag;
+  double exhale_dur_d;      // (double)exhale_duration
+  double food_radius, min_food_dist2;   // 15, 80^2
+  double food_xlo, food_xspan, food_ylo, food_yspan;  // random.uniform(lo, hi) = lo + span*u
+  double food_reward, collision_penalty, time_penalty, efficiency_bonus, prox_w;
+  // fp32 reciprocals for the observation
+  double inv_W, inv_H, inv_pi, inv_R, inv_max_nozzle;
+  float inv_diag;           // 1/sqrt(W^2+H^2)
+  int inhale_dur, exhale_dur, cycle_len, max_steps_wo_food;
+  int F, K;                 // num_food_items, max_observed_food
+  int forced, random_food_count, respawn;
+  uint32_t seed_lo, seed_hi;
+  uint64_t env_base;        // global index of local env 0
+  int64_t n;                // envs in this handle
+  int64_t pitch;            // row pitch (elements) of the SoA state blocks
+};
+
+// SoA state rows (device layout; distinct from the public snapshot layout)
+enum { SF_X = 0, SF_Y, SF_VX, SF_VY, SF_TH, SF_OM, SF_NOZ, SF_WATER, SF_EPRET, SF_FOOD0 };
+enum { SI_PACKED = 0, SI_SSF, SI_FC, SI_RNG, SI_EPLEN, SI_COUNT };
+
+struct DevState {
+  double* f;     // [SF_FOOD0 + 2F][pitch]
+  int32_t* i;    // [SI_COUNT][pitch]
+};
+
+struct DevStats {  // one replica = 16 x 8 B (one 128-B line)
+  unsigned long long v[16];
+};
+enum { ST_STEPS = 0, ST_EPISODES, ST_TERM, ST_TRUNC, ST_COLL, ST_FOOD, ST_EPLEN, ST_REWARD, ST_EPRET };
+#define SALP_STATS_REPLICAS 64
+#define SALP_FIXED_SCALE 1048576.0  /* 2^20 */
+
+// ------------------------------------------------------------------ Philox4x32-10
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+  // ((hi>>5)*2^26 + (lo>>6)) / 2^53 : every operation is exact
+  return ((double)(hi >> 5) * 67108864.0 + (double)(lo >> 6)) * 1.1102230246251565e-16;
+}
+
+__device__ __forceinline__ double pymax(double a, double b) { return (b > a) ? b : a; }
+__device__ __forceinline__ double pymin(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ bool is_none(double fx) { return fx != fx; }
+
+#define SALP_PI 3.141592653589793
+#define SALP_2PI 6.283185307179586
+#define SALP_PIO2 1.5707963267948966
+
+template <int FMAX>
+struct Env {
+  double x, y, vx, vy, th, om, noz, water, epret;
+  double fx[FMAX], fy[FMAX];
+  uint32_t packed;
+  int ssf, fc, eplen;
+  uint32_t rng;
+};
+
+template <int FMAX>
+__device__ __forceinline__ void load_env(Env<FMAX>& e, const DevState& S, const DevParams& P, int64_t i) {
+  const int64_t p = P.pitch;
+  e.x = S.f[SF_X * p + i]; e.y = S.f[SF_Y * p + i];
+  e.vx = S.f[SF_VX * p + i]; e.vy = S.f[SF_VY * p + i];
+  e.th = S.f[SF_TH * p + i]; e.om = S.f[SF_OM * p + i];
+  e.noz = S.f[SF_NOZ * p + i]; e.water = S.f[SF_WATER * p + i];
+  e.epret = S.f[SF_EPRET * p + i];
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) {
+    if (k < P.F) {
+      e.fx[k] = S.f[(SF_FOOD0 + k) * p + i];
+      e.fy[k] = S.f[(SF_FOOD0 + P.F + k) * p + i];
+    } else {
+      e.fx[k] = __builtin_nan(""); e.fy[k] = __builtin_nan("");
+    }
+  }
+  e.packed = (uint32_t)S.i[SI_PACKED * p + i];
+  e.ssf = S.i[SI_SSF * p + i]; e.fc = S.i[SI_FC * p + i];
+  e.rng = (uint32_t)S.i[SI_RNG * p + i]; e.eplen = S.i[SI_EPLEN * p + i];
+}
+
+template <int FMAX>
+__device__ __forceinline__ void store_env(const Env<FMAX>& e, const DevState& S, const DevParams& P, int64_t i) {
+  const int64_t p = P.pitch;
+  S.f[SF_X * p + i] = e.x; S.f[SF_Y * p + i] = e.y;
+  S.f[SF_VX * p + i] = e.vx; S.f[SF_VY * p + i] = e.vy;
+  S.f[SF_TH * p + i] = e.th; S.f[SF_OM * p + i] = e.om;
+  S.f[SF_NOZ * p + i] = e.noz; S.f[SF_WATER * p + i] = e.water;
+  S.f[SF_EPRET * p + i] = e.epret;
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) {
+    if (k < P.F) {
+      S.f[(SF_FOOD0 + k) * p + i] = e.fx[k];
+      S.f[(SF_FOOD0 + P.F + k) * p + i] = e.fy[k];
+    }
+  }
+  S.i[SI_PACKED * p + i] = (int32_t)e.packed;
+  S.i[SI_SSF * p + i] = e.ssf; S.i[SI_FC * p + i] = e.fc;
+  S.i[SI_RNG * p + i] = (int32_t)e.rng; S.i[SI_EPLEN * p + i] = e.eplen;
+}
+
+// One Philox block of this env's draw stream (include/salp_vec.h "Randomness").
+template <int FMAX>
+__device__ __forceinline__ U4 next_block(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
+  U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), e.rng, 0u, P.seed_lo, P.seed_hi);
+  e.rng += 1u;
+  return w;
+}
+
+template <int FMAX>
+__device__ __forceinline__ void draw_xy(Env<FMAX>& e, const DevParams& P, uint64_t genv, double& x, double& y) {
+  const U4 w = next_block(e, P, genv);
+  x = P.food_xlo + P.food_xspan * u53(w.x, w.y);
+  y = P.food_ylo + P.food_yspan * u53(w.z, w.w);
+}
+
+// Ellipse semi-axes implied by the post-step state (see SALP_I_SHAPE_HOLD in salp_vec.h).
+__device__ __forceinline__ void shape_of(const DevParams& P, uint32_t packed, double water, double& a, double& b) {
+  const int phase = bw_phase(packed), timer = bw_timer(packed), dur = bw_dur(packed), hold = bw_hold(packed);
+  if (hold == 7) { a = P.R; b = P.R; return; }
+  if (hold != 0) {
+    const double p = (double)hold / (double)P.inhale_dur;
+    a = P.a_rest + P.da_inh * p; b = P.b_rest + P.db_inh * p; return;
+  }
+  if (phase == 0) { a = P.a_rest; b = P.b_rest; }
+  else if (phase == 1 || timer == 0) { a = P.a_rest + P.da_inh * water; b = P.b_rest + P.db_inh * water; }
+  else {
+    const double p = (double)timer / (double)dur;
+    a = P.ab_full + P.da_exh * p; b = P.ab_full + P.db_exh * p;
+  }
+}
+
+// snake:92-131 _generate_food_positions + legacy:95-117 / snake:133-151 reset
+template <int FMAX>
+__device__ __forceinline__ void reset_env(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
+  e.x = P.half_W; e.y = P.half_H; e.vx = 0.0; e.vy = 0.0; e.th = 0.0; e.om = 0.0;
+  e.noz = 0.0; e.water = 0.0; e.epret = 0.0;
+  e.packed = pack_breath(0, 0, bw_dur(e.packed), 7);
+  e.ssf = 0; e.fc = 0; e.eplen = 0;
+  int nf = P.F;
+  if (P.random_food_count) {  // snake:146 random.randint(1, max(1, base))
+    const U4 w = next_block(e, P, genv);
+    const uint32_t n = (uint32_t)(P.F > 1 ? P.F : 1);
+    nf = 1 + (int)(((uint64_t)w.x * (uint64_t)n) >> 32);
+    if (nf > P.F) nf = P.F;
+  }
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) { e.fx[k] = __builtin_nan(""); e.fy[k] = __builtin_nan(""); }
+#pragma unroll 1
+  for (int f = 0; f < nf; ++f) {
+    double x = 0.0, y = 0.0;
+    int attempts = 0;
+    bool placed = false;
+#pragma unroll 1
+    while (attempts < 100) {
+      draw_xy(e, P, genv, x, y);
+      bool valid = true;
+#pragma unroll
+      for (int k = 0; k < FMAX; ++k) {   // earlier foods occupy slots 0..f-1; the rest are NaN
+        const double dx = x - e.fx[k], dy = y - e.fy[k];
+        if (dx * dx + dy * dy < P.min_food_dist2) valid = false;
+      }
+      {
+        const double dx = x - P.half_W, dy = y - P.half_H;
+        if (dx * dx + dy * dy < P.min_food_dist2) valid = false;
+      }
+      if (valid) { placed = true; break; }
+      ++attempts;
+    }
+    if (!placed) draw_xy(e, P, genv, x, y);
+#pragma unroll
+    for (int k = 0; k < FMAX; ++k) if (k == f) { e.fx[k] = x; e.fy[k] = y; }
+  }
+}
+
+// snake:232-276 _respawn_food
+template <int FMAX>
+__device__ __forceinline__ void respawn_food(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
+  double x = 0.0, y = 0.0;
+  int attempts = 0;
+  bool placed = false;
+#pragma unroll 1
+  while (attempts < 50) {
+    draw_xy(e, P, genv, x, y);
+    bool valid = true;
+    {
+      const double dx = x - e.x, dy = y - e.y;
+      if (dx * dx + dy * dy < P.min_food_dist2) valid = false;
+    }
+#pragma unroll
+    for (int k = 0; k < FMAX; ++k) {
+      const double dx = x - e.fx[k], dy = y - e.fy[k];
+      if (dx * dx + dy * dy < P.min_food_dist2) valid = false;
+    }
+    if (valid) { placed = true; break; }
+    ++attempts;
+  }
+  if (!placed) draw_xy(e, P, genv, x, y);
+  bool done = false;
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) {
+    if (!done && k < P.F && is_none(e.fx[k])) { e.fx[k] = x; e.fy[k] = y; done = true; }
+  }
+}
+
+// legacy:261-314 _apply_jet_thrust (water is the value BEFORE this step's decay)
+template <int FMAX>
+__device__ __forceinline__ void apply_jet_thrust(Env<FMAX>& e, const DevParams& P, uint64_t genv, double r) {
+  const double T = (P.thrust_force * e.water) * 0.4;
+  const double phi = e.th - e.noz;
+  double s, c;
+  sincos(phi, &s, &c);
+  e.vx = e.vx + (c * T) * 0.012;
+  e.vy = e.vy + (s * T) * 0.012;
+  const double nn = -e.noz;
+  const double primary = (nn * T) * 0.0002;
+  const double arm = r * 0.7;
+  const double perp = T * sin(nn);
+  const double moment = (perp * arm) * 0.00005;
+  const double shape = ((nn * T) * e.water) * 0.00003;
+  e.om = e.om + ((primary + moment) + shape);
+  const double side = phi + SALP_PIO2;
+  const double S = (T * fabs(e.noz)) * 0.3;
+  double ss, sc;
+  sincos(side, &ss, &sc);
+  e.vx = e.vx + (sc * S) * 0.008;
+  e.vy = e.vy + (ss * S) * 0.008;
+  const U4 w = next_block(e, P, genv);
+  const double u = u53(w.x, w.y);
+  const double na = phi + (u - 0.5) * 0.05;
+  const double nf = T * 0.04;
+  double ns, nc;
+  sincos(na, &ns, &nc);
+  e.vx = e.vx + (nc * nf) * 0.002;
+  e.vy = e.vy + (ns * nf) * 0.002;
+}
+
+struct StepOut {
+  double rmax;   // max(ellipse_a, ellipse_b) of this step
+  float reward;
+  bool terminated, truncated, collision, collected;
+};
+
+// One reference step (legacy:119-156 under snake:157-189), without autoreset / observation.
+template <int FMAX, bool FORCED>
+__device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, uint64_t genv, float a0, float a1) {
+  int phase = bw_phase(e.packed), timer = bw_timer(e.packed), dur = bw_dur(e.packed);
+  // legacy:121-135
+  double nd;
+  bool inhaling;
+  if (FORCED) {
+    nd = (double)a0;
+    const int tm = (P.cycle_len > 255) ? timer : (timer % P.cycle_len);
+    inhaling = tm < P.inhale_dur;
+  } else {
+    inhaling = a0 > 0.5f;
+    nd = (double)a1;
+  }
+  const double target = nd * P.max_nozzle;
+  // legacy:169-182 _update_nozzle
+  {
+    const double diff = target - e.noz;
+    double nz;
+    if (fabs(diff) > P.nozzle_rate) nz = (diff > 0) ? (e.noz + P.nozzle_rate) : (e.noz - P.nozzle_rate);
+    else nz = target;
+    e.noz = pymax(-P.max_nozzle, pymin(P.max_nozzle, nz));
+  }
+  // legacy:184-259 _update_breathing_cycle
+  double a, b;
+  int hold = 0;
+  bool thrust = false;
+  double water_next = e.water;
+  {
+    const int tnew = timer + 1;
+    const double den = (phase == 2) ? (double)dur : (double)P.inhale_dur;
+    const double p = (double)tnew / den;
+    if (phase == 0) {
+      a = P.a_rest; b = P.b_rest;
+      if (inhaling) { phase = 1; timer = 0; }
+    } else if (phase == 1) {
+      if (inhaling && timer < P.inhale_dur) {
+        timer = tnew;
+        a = P.a_rest + P.da_inh * p; b = P.b_rest + P.db_inh * p;
+        water_next = p;
+      } else {
+        a = P.a_rest + P.da_inh * e.water; b = P.b_rest + P.db_inh * e.water;  // unchanged ellipse
+        if (e.water > 0.05) {
+          phase = 2; timer = 0;
+          dur = (int)(P.exhale_dur_d * pymax(e.water, 0.3));
+        } else {
+          hold = (timer >= 1 && timer <= 6) ? timer : 0;
+          phase = 0; timer = 0; water_next = 0.0;
+        }
+      }
+    } else {
+      if (p <= 1.0) {
+        timer = tnew;
+        a = P.ab_full + P.da_exh * p; b = P.ab_full + P.db_exh * p;
+        thrust = (0.1 <= p) && (p <= 0.5);
+        const double v = e.water * (1.0 - p);
+        water_next = (v > 0) ? v : 0.0;
+      } else {
+        a = P.ab_full + P.da_exh * 1.0; b = P.ab_full + P.db_exh * 1.0;  // ellipse of the last exhale step
+        phase = 0; timer = 0; water_next = 0.0;
+      }
+    }
+  }
+  const double r = pymax(a, b);
+  if (thrust) apply_jet_thrust(e, P, genv, r);
+  e.water = water_next;
+  e.packed = pack_breath(phase, timer, dur, hold);
+  // legacy:316-352 _update_physics
+  e.vx = e.vx * P.drag; e.vy = e.vy * P.drag; e.om = e.om * P.ang_drag;
+  e.x = e.x + e.vx; e.y = e.y + e.vy; e.th = e.th + e.om;
+#pragma unroll 1
+  for (int it = 0; it < 8 && e.th > SALP_PI; ++it) e.th -= SALP_2PI;
+#pragma unroll 1
+  for (int it = 0; it < 8 && e.th < -SALP_PI; ++it) e.th += SALP_2PI;
+  {
+    const double m = P.margin + r;
+    const double hx = P.W - m, hy = P.H - m;
+    if (e.x < m) { e.x = m; e.vx = fabs(e.vx) * 0.4; e.om = e.om * 0.7; }
+    else if (e.x > hx) { e.x = hx; e.vx = -fabs(e.vx) * 0.4; e.om = e.om * 0.7; }
+    if (e.y < m) { e.y = m; e.vy = fabs(e.vy) * 0.4; e.om = e.om * 0.7; }
+    else if (e.y > hy) { e.y = hy; e.vy = -fabs(e.vy) * 0.4; e.om = e.om * 0.7; }
+  }
+  StepOut o;
+  o.rmax = r;
+  // snake:204-217 _check_food_collection (first live food inside the capture radius)
+  o.collected = false;
+  {
+    const double cr = r + P.food_radius;
+    const double cr2 = cr * cr;
+#pragma unroll
+    for (int k = 0; k < FMAX; ++k) {
+      const double dx = e.x - e.fx[k], dy = e.y - e.fy[k];
+      if (!o.collected && (dx * dx + dy * dy < cr2)) {
+        o.collected = true; e.fx[k] = __builtin_nan(""); e.fy[k] = __builtin_nan("");
+      }
+    }
+  }
+  // snake:219-230 _check_wall_collision
+  o.collision = (e.x - r <= P.margin) || (e.x + r >= P.wall_hi_x) || (e.y - r <= P.margin) || (e.y + r >= P.wall_hi_y);
+  // snake:278-327 _calculate_snake_reward
+  double rew = 0.0;
+  if (o.collected) {
+    rew += P.food_reward;
+    if (P.efficiency_bonus > 0) rew += P.efficiency_bonus * (double)(P.max_steps_wo_food - e.ssf);
+  }
+  if (o.collision) rew += P.collision_penalty;
+  if (P.prox_w > 0) {
+    double bd2 = 0.0, bdx = 0.0, bdy = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < FMAX; ++k) {
+      const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
+      const double d2 = dx * dx + dy * dy;
+      if (!is_none(e.fx[k]) && (!any || d2 < bd2)) { any = true; bd2 = d2; bdx = dx; bdy = dy; }
+    }
+    if (any) {
+      // alignment = cos(wrap(atan2(dy,dx) - theta)) = cos(atan2(dy,dx) - theta); fp32 is enough
+      // for a term that only leaves the simulator (snake:301-322)
+      const float ang = atan2f((float)bdy, (float)bdx) - (float)e.th;
+      rew += P.prox_w * (double)cosf(ang);
+    }
+  }
+  rew += P.time_penalty;
+  // snake:171-189
+  e.ssf += 1;
+  if (o.collected) {
+    e.fc += 1;
+    e.ssf = 0;
+    if (P.respawn) respawn_food(e, P, genv);
+  }
+  o.terminated = false; o.truncated = false;
+  if (o.collision) o.terminated = true;
+  else if (e.ssf > P.max_steps_wo_food) o.truncated = true;
+  else if (!P.respawn) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < FMAX; ++k) any = any || !is_none(e.fx[k]);
+    if (!any) o.terminated = true;
+  }
+  e.eplen += 1;
+  e.epret += rew;
+  o.reward = (float)rew;
+  return o;
+}
+
+// legacy:371-388 + snake:366-428: writes the obs row (10 + 4K + 2 floats) to `row` (LDS or global).
+// rmax = max(ellipse_a, ellipse_b) of the current state.
+template <int FMAX, int KMAX>
+__device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, double rmax, float* row) {
+  const int K = (KMAX == 3) ? 3 : P.K;
+  row[0] = (float)(e.x * P.inv_W);
+  row[1] = (float)(e.y * P.inv_H);
+  row[2] = (float)(e.vx * 0.2);
+  row[3] = (float)(e.vy * 0.2);
+  row[4] = (float)(e.th * P.inv_pi);
+  row[5] = (float)(e.om * 10.0);
+  row[6] = (float)(rmax * P.inv_R);
+  row[7] = (float)bw_phase(e.packed) * 0.5f;
+  row[8] = (float)e.water;
+  row[9] = (float)(e.noz * P.inv_max_nozzle);
+  // squared distances of live foods in fp64 (the sort key), distances in fp32 (the outputs)
+  double d2[FMAX];
+  float d[FMAX];
+  int cnt = 0;
+  uint32_t live = 0;
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) {
+    const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
+    d2[k] = dx * dx + dy * dy;
+    const bool ok = !is_none(e.fx[k]);
+    d[k] = __fsqrt_rn((float)d2[k]);
+    if (ok) { live |= (1u << k); ++cnt; }
+  }
+  const float th = (float)e.th;
+  float dsum = 0.f;
+  // K nearest, nearest first; ties keep slot order (stable sort, snake:382)
+  uint32_t left = live;
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    if (s < K) {
+      double bd2 = 0.0;
+      float bd = 0.f, bx = 0.f, by = 0.f;
+      int bi = -1;
+#pragma unroll
+      for (int k = 0; k < FMAX; ++k) {
+        const bool cand = ((left >> k) & 1u) && (bi < 0 || d2[k] < bd2);
+        if (cand) { bi = k; bd2 = d2[k]; bd = d[k]; bx = (float)(e.fx[k] - e.x); by = (float)(e.fy[k] - e.y); }
+      }
+      if (bi >= 0) {
+        left &= ~(1u << bi);
+        dsum += bd;
+        float rel = atan2f(by, bx) - th;
+        if (rel > 3.14159265358979f) rel -= 6.28318530717959f;
+        if (rel < -3.14159265358979f) rel += 6.28318530717959f;
+        row[10 + 4 * s + 0] = bx * (float)P.inv_W;
+        row[10 + 4 * s + 1] = by * (float)P.inv_H;
+        row[10 + 4 * s + 2] = bd * P.inv_diag;
+        row[10 + 4 * s + 3] = rel * 0.318309886183791f;
+      } else {
+        row[10 + 4 * s + 0] = 0.f; row[10 + 4 * s + 1] = 0.f; row[10 + 4 * s + 2] = 1.f; row[10 + 4 * s + 3] = 0.f;
+      }
+    }
+  }
+  // the mean distance runs over ALL live foods (snake:418-420), not only the K observed
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) if ((left >> k) & 1u) dsum += d[k];
+  const float fcnt = (float)cnt;
+  row[10 + 4 * K + 0] = fminf(fcnt / 10.0f, 1.0f);
+  row[10 + 4 * K + 1] = (cnt > 0) ? (dsum / fcnt) * P.inv_diag : 1.0f;
+}
+
+}  // namespace salp

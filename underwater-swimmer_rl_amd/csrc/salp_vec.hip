@@ -1,0 +1,699 @@
+// salp_vec.hip — fused SALP step/rollout kernels for gfx950 and the C ABI of include/salp_vec.h.
+//
+// Kernel design:
+//   * one SALP per lane, 256-thread workgroups (4 wavefronts), env index = blockIdx*256 + tid;
+//   * state is struct-of-arrays in HBM (row-major [quantity][env], 8-byte and 4-byte rows), read
+//     once at kernel entry, held in VGPRs across the `horizon` steps, written once at exit;
+//   * per step each wavefront stages its 64 observation rows (64 x obs_dim floats) in its private
+//     LDS tile and streams them out as whole 16-byte-per-lane coalesced stores, so the
+//     [horizon][n_envs][obs_dim] row-major output is written as contiguous 64*obs_dim*4-byte
+//     runs per wavefront; actions are prefetched one step ahead;
+//   * episode / reward statistics are reduced with wavefront shuffles, then one 64-bit integer
+//     atomic per block and statistic into one of 64 line-sized replicas (order-independent).
+// No MFMA: there is no dense contraction on this path; the bound is HBM write bandwidth.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include <new>
+#include <string>
+
+#include "../../include/salp_vec.h"
+#include "salp_device.h"
+
+using namespace salp;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWave = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct IOPtrs {
+  const float* act;       // [H][n][act_dim] or null (device-generated)
+  float* obs;             // [H][n][obs_dim]
+  float* reward;          // [H][n]
+  uint8_t* terminated;    // [H][n]
+  uint8_t* truncated;     // [H][n]
+  float* final_obs;       // [H][n][obs_dim] rows of finished envs only
+  int32_t* info;          // [H][n][3]
+  float* act_out;         // [H][n][act_dim]
+  DevStats* stats;        // [SALP_STATS_REPLICAS] or null
+  int64_t global_step;    // step index of t = 0 (device-generated actions)
+};
+
+// Streams one wavefront's staged tile (rows x Q float4, LDS pitch PITCH floats) to global memory
+// as contiguous 16-B-per-lane stores.  `rows` = live rows of this wavefront (<= 64).
+template <int PITCH>
+__device__ __forceinline__ void flush_tile(const float* tile, float* __restrict__ gbase, int Q, int rows, int lane) {
+  const int total = rows * Q;  // float4 count
+  for (int f = lane; f < total; f += kWave) {
+    const int r = f / Q;
+    const int c = f - r * Q;
+    const float4 v = *reinterpret_cast<const float4*>(tile + r * PITCH + 4 * c);
+    *reinterpret_cast<float4*>(gbase + (int64_t)f * 4) = v;
+  }
+}
+
+template <int FMAX, int KMAX, bool FORCED>
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H) {
+  constexpr int QMAX = 3 + KMAX;          // float4 per observation row
+  constexpr int PITCH = 4 * QMAX + 4;     // LDS row pitch in floats (pad 16 B: conflict-free b128 writes)
+  __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * kWave * PITCH];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid / kWave;
+  const int64_t env0 = (int64_t)blockIdx.x * kBlock + (int64_t)wave * kWave;  // first env of this wavefront
+  const int64_t env = env0 + lane;
+  const bool active = env < P.n;
+  const int64_t envc = active ? env : (P.n - 1);
+  const int rows = (int)((P.n - env0) < kWave ? ((P.n - env0) > 0 ? (P.n - env0) : 0) : kWave);
+  const uint64_t genv = P.env_base + (uint64_t)envc;
+  const int K = (KMAX == 3) ? 3 : P.K;
+  const int Q = 3 + K;
+  const int OD = 4 * Q;
+  const int AD = FORCED ? 1 : 2;
+  float* tile = lds + wave * kWave * PITCH;
+  float* myrow = tile + lane * PITCH;
+
+  Env<FMAX> e;
+  load_env(e, S, P, envc);
+
+  // per-lane statistics
+  double st_reward = 0.0, st_epret = 0.0;
+  int st_eps = 0, st_term = 0, st_trunc = 0, st_coll = 0, st_food = 0, st_eplen = 0;
+
+  float a0 = 0.f, a1 = 0.f;
+  if (io.act) {
+    a0 = io.act[envc * AD];
+    if (!FORCED) a1 = io.act[envc * AD + 1];
+  }
+
+#pragma unroll 1
+  for (int t = 0; t < H; ++t) {
+    const int64_t rowbase = (int64_t)t * P.n;
+    float c0 = a0, c1 = a1;
+    if (io.act) {
+      if (t + 1 < H) {  // prefetch the next step's action
+        const int64_t nb = (rowbase + P.n + envc) * AD;
+        a0 = io.act[nb];
+        if (!FORCED) a1 = io.act[nb + 1];
+      }
+    } else {
+      const uint32_t ts = (uint32_t)(io.global_step + t);
+      const U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts, 1u, P.seed_lo, P.seed_hi);
+      if (FORCED) {
+        c0 = (float)(w.x >> 8) * 1.1920928955078125e-7f - 1.0f;
+      } else {
+        c0 = (float)(w.x >> 8) * 5.9604644775390625e-8f;
+        const U4 w2 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts, 2u, P.seed_lo, P.seed_hi);
+        c1 = (float)(w2.x >> 8) * 1.1920928955078125e-7f - 1.0f;
+      }
+      if (io.act_out && active) {
+        io.act_out[(rowbase + env) * AD] = c0;
+        if (!FORCED) io.act_out[(rowbase + env) * AD + 1] = c1;
+      }
+    }
+
+    const StepOut o = step_env<FMAX, FORCED>(e, P, genv, c0, c1);
+    const bool done = o.terminated || o.truncated;
+    double rmax = o.rmax;
+
+    if (active) {
+      if (io.reward) io.reward[rowbase + env] = o.reward;
+      if (io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
+      if (io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
+      if (io.info) {
+        int32_t* ip = io.info + (rowbase + env) * SALP_INFO_COLS;
+        ip[SALP_INFO_FOOD_COLLECTED] = e.fc;
+        ip[SALP_INFO_STEPS_SINCE_FOOD] = e.ssf;
+        ip[SALP_INFO_COLLISION] = o.collision ? 1 : 0;
+      }
+    }
+    st_reward += (double)o.reward;
+    st_food += o.collected ? 1 : 0;
+    st_coll += o.collision ? 1 : 0;
+
+    if (__any(done)) {  // rare: same-step autoreset (snake has none; Gymnasium VectorEnv semantics)
+      if (done) {
+        st_eps += 1; st_term += o.terminated ? 1 : 0; st_trunc += o.truncated ? 1 : 0;
+        st_eplen += e.eplen; st_epret += e.epret;
+        if (io.final_obs && active) observe<FMAX, KMAX>(e, P, rmax, io.final_obs + (rowbase + env) * OD);
+        reset_env(e, P, genv);
+        rmax = P.R;
+      }
+    }
+
+    if (io.obs) {
+      observe<FMAX, KMAX>(e, P, rmax, myrow);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      flush_tile<PITCH>(tile, io.obs + (rowbase + env0) * OD, Q, rows, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+
+  if (active) store_env(e, S, P, env);
+
+  if (io.stats) {
+    // wavefront shuffles -> LDS across the 4 wavefronts -> one atomic per block and statistic
+    __shared__ long long red[kBlock / kWave][10];
+    if (!active) { st_reward = 0.0; st_epret = 0.0; st_eps = st_term = st_trunc = st_coll = st_food = st_eplen = 0; }
+    const double wr = wave_sum(st_reward), we = wave_sum(st_epret);
+    const int weps = wave_sum(st_eps), wterm = wave_sum(st_term), wtrunc = wave_sum(st_trunc);
+    const int wcoll = wave_sum(st_coll), wfood = wave_sum(st_food), weplen = wave_sum(st_eplen);
+    const int wact = wave_sum(active ? 1 : 0);
+    if (lane == 0) {
+      red[wave][ST_STEPS] = (long long)wact * H;
+      red[wave][ST_EPISODES] = weps; red[wave][ST_TERM] = wterm; red[wave][ST_TRUNC] = wtrunc;
+      red[wave][ST_COLL] = wcoll; red[wave][ST_FOOD] = wfood; red[wave][ST_EPLEN] = weplen;
+      red[wave][ST_REWARD] = __double2ll_rn(wr * SALP_FIXED_SCALE);
+      red[wave][ST_EPRET] = __double2ll_rn(we * SALP_FIXED_SCALE);
+    }
+    __syncthreads();
+    if (tid <= ST_EPRET) {
+      long long v = 0;
+#pragma unroll
+      for (int w = 0; w < kBlock / kWave; ++w) v += red[w][tid];
+      if (v != 0) atomicAdd(&io.stats[blockIdx.x % SALP_STATS_REPLICAS].v[tid], (unsigned long long)v);
+    }
+  }
+}
+
+// reset(mask) + observation
+template <int FMAX, int KMAX>
+__global__ __launch_bounds__(kBlock) void salp_reset_kernel(DevParams P, DevState S, const uint8_t* mask, float* obs, int do_reset) {
+  const int64_t env = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (env >= P.n) return;
+  const uint64_t genv = P.env_base + (uint64_t)env;
+  Env<FMAX> e;
+  load_env(e, S, P, env);
+  if (do_reset && (!mask || mask[env])) {
+    reset_env(e, P, genv);
+    store_env(e, S, P, env);
+  }
+  if (obs) {
+    const int K = (KMAX == 3) ? 3 : P.K;
+    double a, b;
+    shape_of(P, e.packed, e.water, a, b);
+    observe<FMAX, KMAX>(e, P, pymax(a, b), obs + env * (12 + 4 * K));
+  }
+}
+
+// public snapshot <-> device layout
+__global__ void salp_get_state_kernel(DevParams P, DevState S, double* f64, int32_t* i32) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const int64_t p = P.pitch, n = P.n;
+  const uint32_t packed = (uint32_t)S.i[SI_PACKED * p + i];
+  if (f64) {
+    f64[SALP_F_X * n + i] = S.f[SF_X * p + i]; f64[SALP_F_Y * n + i] = S.f[SF_Y * p + i];
+    f64[SALP_F_VX * n + i] = S.f[SF_VX * p + i]; f64[SALP_F_VY * n + i] = S.f[SF_VY * p + i];
+    f64[SALP_F_THETA * n + i] = S.f[SF_TH * p + i]; f64[SALP_F_OMEGA * n + i] = S.f[SF_OM * p + i];
+    f64[SALP_F_NOZZLE * n + i] = S.f[SF_NOZ * p + i];
+    const double water = S.f[SF_WATER * p + i];
+    f64[SALP_F_WATER * n + i] = water;
+    double a, b;
+    shape_of(P, packed, water, a, b);
+    f64[SALP_F_ELLIPSE_A * n + i] = a; f64[SALP_F_ELLIPSE_B * n + i] = b;
+    for (int k = 0; k < 2 * P.F; ++k) f64[(SALP_F_FOOD0 + k) * n + i] = S.f[(SF_FOOD0 + k) * p + i];
+  }
+  if (i32) {
+    i32[SALP_I_PHASE * n + i] = bw_phase(packed); i32[SALP_I_TIMER * n + i] = bw_timer(packed);
+    i32[SALP_I_EXHALE_DUR * n + i] = bw_dur(packed); i32[SALP_I_SHAPE_HOLD * n + i] = bw_hold(packed);
+    i32[SALP_I_STEPS_SINCE_FOOD * n + i] = S.i[SI_SSF * p + i];
+    i32[SALP_I_FOOD_COLLECTED * n + i] = S.i[SI_FC * p + i];
+    i32[SALP_I_RNG_COUNTER * n + i] = S.i[SI_RNG * p + i];
+    i32[SALP_I_EPISODE_LENGTH * n + i] = S.i[SI_EPLEN * p + i];
+  }
+}
+
+__global__ void salp_set_state_kernel(DevParams P, DevState S, const double* f64, const int32_t* i32) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const int64_t p = P.pitch, n = P.n;
+  if (f64) {
+    S.f[SF_X * p + i] = f64[SALP_F_X * n + i]; S.f[SF_Y * p + i] = f64[SALP_F_Y * n + i];
+    S.f[SF_VX * p + i] = f64[SALP_F_VX * n + i]; S.f[SF_VY * p + i] = f64[SALP_F_VY * n + i];
+    S.f[SF_TH * p + i] = f64[SALP_F_THETA * n + i]; S.f[SF_OM * p + i] = f64[SALP_F_OMEGA * n + i];
+    S.f[SF_NOZ * p + i] = f64[SALP_F_NOZZLE * n + i]; S.f[SF_WATER * p + i] = f64[SALP_F_WATER * n + i];
+    for (int k = 0; k < P.F; ++k) {
+      double fx = f64[(SALP_F_FOOD0 + k) * n + i], fy = f64[(SALP_F_FOOD0 + P.F + k) * n + i];
+      if (fx != fx || fy != fy) { fx = __builtin_nan(""); fy = __builtin_nan(""); }
+      S.f[(SF_FOOD0 + k) * p + i] = fx; S.f[(SF_FOOD0 + P.F + k) * p + i] = fy;
+    }
+  }
+  if (i32) {
+    S.i[SI_PACKED * p + i] = (int32_t)pack_breath(i32[SALP_I_PHASE * n + i], i32[SALP_I_TIMER * n + i],
+                                                  i32[SALP_I_EXHALE_DUR * n + i], i32[SALP_I_SHAPE_HOLD * n + i]);
+    S.i[SI_SSF * p + i] = i32[SALP_I_STEPS_SINCE_FOOD * n + i];
+    S.i[SI_FC * p + i] = i32[SALP_I_FOOD_COLLECTED * n + i];
+    S.i[SI_RNG * p + i] = i32[SALP_I_RNG_COUNTER * n + i];
+    S.i[SI_EPLEN * p + i] = i32[SALP_I_EPISODE_LENGTH * n + i];
+  }
+}
+
+// ------------------------------------------------------------------ host side
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess)                                                                          \
+      return fail(_e == hipErrorOutOfMemory ? SALP_ERR_OOM : SALP_ERR_HIP,                         \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                              \
+  } while (0)
+
+}  // namespace
+
+struct salp_vec {
+  salp_config_t cfg;
+  DevParams P;
+  DevState S;
+  int device;
+  int64_t n;
+  uint64_t seed;
+  int64_t global_step;
+  int obs_dim, act_dim, F, K;
+  int fmax, kmax;
+  DevStats* stats;       // device, SALP_STATS_REPLICAS replicas
+  int stats_enabled;
+  // staging for host-pointer calls (grown on demand)
+  void* stage;
+  size_t stage_bytes;
+  size_t nf_rows;
+};
+
+namespace {
+
+DevParams make_params(const salp_config_t& c, int64_t n, int64_t pitch, uint64_t seed, int64_t base) {
+  DevParams P;
+  memset(&P, 0, sizeof(P));
+  P.W = (double)c.width; P.H = (double)c.height;
+  P.half_W = (double)c.width / 2; P.half_H = (double)c.height / 2;
+  P.margin = c.tank_margin;
+  P.wall_hi_x = (double)c.width - c.tank_margin; P.wall_hi_y = (double)c.height - c.tank_margin;
+  P.R = c.base_radius;
+  P.a_rest = c.base_radius * 1.3; P.b_rest = c.base_radius * 0.8; P.ab_full = c.base_radius * 1.1;
+  P.da_inh = P.ab_full - P.a_rest; P.db_inh = P.ab_full - P.b_rest;
+  P.da_exh = P.a_rest - P.ab_full; P.db_exh = P.b_rest - P.ab_full;
+  P.max_nozzle = c.max_nozzle_angle; P.nozzle_rate = c.nozzle_response_rate;
+  P.thrust_force = c.max_thrust_force; P.drag = c.drag_coefficient; P.ang_drag = c.angular_drag;
+  P.exhale_dur_d = (double)c.exhale_duration;
+  P.food_radius = c.food_radius; P.min_food_dist2 = c.min_food_distance * c.min_food_distance;
+  P.food_xlo = c.tank_margin + c.food_radius;
+  P.food_xspan = ((double)c.width - c.tank_margin - c.food_radius) - P.food_xlo;
+  P.food_ylo = P.food_xlo;
+  P.food_yspan = ((double)c.height - c.tank_margin - c.food_radius) - P.food_ylo;
+  P.food_reward = c.food_reward; P.collision_penalty = c.collision_penalty;
+  P.time_penalty = c.time_penalty; P.efficiency_bonus = c.efficiency_bonus;
+  P.prox_w = c.proximity_reward_weight;
+  P.inv_W = 1.0 / P.W; P.inv_H = 1.0 / P.H; P.inv_pi = 1.0 / 3.141592653589793;
+  P.inv_R = 1.0 / c.base_radius; P.inv_max_nozzle = 1.0 / c.max_nozzle_angle;
+  P.inv_diag = (float)(1.0 / sqrt(P.W * P.W + P.H * P.H));
+  P.inhale_dur = c.inhale_duration; P.exhale_dur = c.exhale_duration;
+  P.cycle_len = c.inhale_duration + c.exhale_duration + c.rest_duration;
+  P.max_steps_wo_food = c.max_steps_without_food;
+  P.F = c.num_food_items; P.K = c.max_observed_food;
+  P.forced = c.forced_breathing != 0; P.random_food_count = c.random_food_count != 0;
+  P.respawn = c.respawn_food != 0;
+  P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
+  P.env_base = (uint64_t)base; P.n = n; P.pitch = pitch;
+  return P;
+}
+
+int validate(const salp_config_t* c) {
+  if (!c) return fail(SALP_ERR_INVALID, "config is NULL");
+  if (c->struct_size != sizeof(salp_config_t))
+    return fail(SALP_ERR_INVALID, "salp_config_t.struct_size mismatch (ABI version skew)");
+  if (c->width <= 0 || c->height <= 0) return fail(SALP_ERR_INVALID, "width/height must be positive");
+  if (c->num_food_items < 0 || c->num_food_items > SALP_MAX_FOOD)
+    return fail(SALP_ERR_INVALID, "num_food_items must be in [0, SALP_MAX_FOOD]");
+  if (c->max_observed_food < 0 || c->max_observed_food > SALP_MAX_OBSERVED_FOOD)
+    return fail(SALP_ERR_INVALID, "max_observed_food must be in [0, SALP_MAX_OBSERVED_FOOD]");
+  if (c->inhale_duration < 1 || c->inhale_duration > 255 || c->exhale_duration < 4 || c->exhale_duration > 254)
+    return fail(SALP_ERR_INVALID, "inhale_duration in [1,255], exhale_duration in [4,254] required");
+  if (c->rest_duration < 0) return fail(SALP_ERR_INVALID, "rest_duration must be >= 0");
+  if (!(c->base_radius > 0) || !(c->max_nozzle_angle > 0))
+    return fail(SALP_ERR_INVALID, "base_radius and max_nozzle_angle must be positive");
+  return SALP_OK;
+}
+
+typedef void (*rollout_fn)(DevParams, DevState, IOPtrs, int);
+typedef void (*reset_fn)(DevParams, DevState, const uint8_t*, float*, int);
+
+template <int FMAX, int KMAX>
+rollout_fn pick_rollout(bool forced) {
+  return forced ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true> : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false>;
+}
+
+rollout_fn rollout_kernel_for(const salp_vec* h) {
+  const bool forced = h->P.forced != 0;
+  if (h->kmax == 3) {
+    if (h->fmax == 1) return pick_rollout<1, 3>(forced);
+    if (h->fmax == 4) return pick_rollout<4, 3>(forced);
+    return pick_rollout<16, 3>(forced);
+  }
+  return pick_rollout<16, 8>(forced);
+}
+reset_fn reset_kernel_for(const salp_vec* h) {
+  if (h->kmax == 3) {
+    if (h->fmax == 1) return (reset_fn)salp_reset_kernel<1, 3>;
+    if (h->fmax == 4) return (reset_fn)salp_reset_kernel<4, 3>;
+    return (reset_fn)salp_reset_kernel<16, 3>;
+  }
+  return (reset_fn)salp_reset_kernel<16, 8>;
+}
+
+int ensure_stage(salp_vec* h, size_t bytes) {
+  if (bytes <= h->stage_bytes) return SALP_OK;
+  if (h->stage) { (void)hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+  HIP_TRY(hipMalloc(&h->stage, bytes));
+  h->stage_bytes = bytes;
+  return SALP_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Bump {  // carve sub-buffers out of the staging allocation
+  char* base; size_t off;
+  template <class T> T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
+  const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
+  rollout_fn fn = rollout_kernel_for(h);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H);
+  HIP_TRY(hipGetLastError());
+  return SALP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* salp_last_error(void) { return g_err.c_str(); }
+int salp_abi_version(void) { return SALP_ABI_VERSION; }
+
+int salp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int salp_config_default(salp_config_t* c) {
+  if (!c) return fail(SALP_ERR_INVALID, "cfg is NULL");
+  memset(c, 0, sizeof(*c));
+  c->struct_size = (uint32_t)sizeof(*c);
+  c->width = 800; c->height = 600; c->num_food_items = 5; c->max_observed_food = 3;
+  c->max_steps_without_food = 1500; c->forced_breathing = 1; c->random_food_count = 0; c->respawn_food = 1;
+  c->food_reward = 10.0; c->collision_penalty = -50.0; c->time_penalty = -0.1; c->efficiency_bonus = 1.0;
+  c->proximity_reward_weight = 0.0;
+  c->tank_margin = 50.0; c->base_radius = 30.0; c->max_thrust_force = 100.0; c->drag_coefficient = 0.98;
+  c->angular_drag = 0.95; c->max_nozzle_angle = 3.141592653589793 / 3; c->nozzle_response_rate = 0.05;
+  c->food_radius = 15.0; c->min_food_distance = 80.0;
+  c->inhale_duration = 120; c->exhale_duration = 150; c->rest_duration = 60;
+  return SALP_OK;
+}
+
+int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uint64_t seed,
+                    int64_t env_index_base, salp_vec_t** out) {
+  if (!out) return fail(SALP_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int rc = validate(cfg);
+  if (rc != SALP_OK) return rc;
+  if (n_envs <= 0 || n_envs > ((int64_t)1 << 31) - kBlock) return fail(SALP_ERR_INVALID, "n_envs out of range");
+  if (env_index_base < 0) return fail(SALP_ERR_INVALID, "env_index_base must be >= 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(SALP_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(SALP_ERR_NO_DEVICE, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+
+  salp_vec* h = new (std::nothrow) salp_vec();
+  if (!h) return fail(SALP_ERR_OOM, "host allocation failed");
+  memset(h, 0, sizeof(*h));
+  h->cfg = *cfg; h->device = device_id; h->n = n_envs; h->seed = seed; h->global_step = 0;
+  h->F = cfg->num_food_items; h->K = cfg->max_observed_food;
+  h->obs_dim = 10 + 4 * h->K + 2; h->act_dim = cfg->forced_breathing ? 1 : 2;
+  h->kmax = (h->K == 3) ? 3 : 8;
+  h->fmax = (h->kmax == 3) ? (h->F <= 1 ? 1 : (h->F <= 4 ? 4 : 16)) : 16;
+  const int64_t pitch = (int64_t)align_up((size_t)n_envs, 64);
+  h->P = make_params(*cfg, n_envs, pitch, seed, env_index_base);
+  h->nf_rows = (size_t)(SF_FOOD0 + 2 * h->F);
+  h->stats_enabled = 1;
+
+  hipError_t e1 = hipMalloc((void**)&h->S.f, h->nf_rows * (size_t)pitch * sizeof(double));
+  hipError_t e2 = (e1 == hipSuccess) ? hipMalloc((void**)&h->S.i, (size_t)SI_COUNT * (size_t)pitch * sizeof(int32_t)) : e1;
+  hipError_t e3 = (e2 == hipSuccess) ? hipMalloc((void**)&h->stats, SALP_STATS_REPLICAS * sizeof(DevStats)) : e2;
+  if (e3 != hipSuccess) {
+    std::string m = std::string("hipMalloc(state): ") + hipGetErrorString(e3);
+    salp_vec_destroy(h);
+    return fail(e3 == hipErrorOutOfMemory ? SALP_ERR_OOM : SALP_ERR_HIP, m);
+  }
+  hipError_t e = hipMemset(h->S.f, 0, h->nf_rows * (size_t)pitch * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->S.i, 0, (size_t)SI_COUNT * (size_t)pitch * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemset(h->stats, 0, SALP_STATS_REPLICAS * sizeof(DevStats));
+  if (e != hipSuccess) {
+    std::string m = std::string("hipMemset(state): ") + hipGetErrorString(e);
+    salp_vec_destroy(h);
+    return fail(SALP_ERR_HIP, m);
+  }
+  // initial reset of every env (consumes the first draws of each env's stream)
+  rc = salp_vec_reset(h, nullptr, nullptr, SALP_DEVICE_PTRS, nullptr);
+  if (rc == SALP_OK) {
+    hipError_t es = hipDeviceSynchronize();
+    if (es != hipSuccess) rc = fail(SALP_ERR_HIP, std::string("initial reset: ") + hipGetErrorString(es));
+  }
+  if (rc != SALP_OK) { std::string m = g_err; salp_vec_destroy(h); g_err = m; return rc; }
+  *out = h;
+  return SALP_OK;
+}
+
+void salp_vec_destroy(salp_vec_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->S.f) (void)hipFree(h->S.f);
+  if (h->S.i) (void)hipFree(h->S.i);
+  if (h->stats) (void)hipFree(h->stats);
+  if (h->stage) (void)hipFree(h->stage);
+  delete h;
+}
+
+int64_t salp_vec_num_envs(const salp_vec_t* h) { return h ? h->n : 0; }
+int salp_vec_obs_dim(const salp_vec_t* h) { return h ? h->obs_dim : 0; }
+int salp_vec_act_dim(const salp_vec_t* h) { return h ? h->act_dim : 0; }
+int salp_vec_num_food(const salp_vec_t* h) { return h ? h->F : 0; }
+int salp_vec_device(const salp_vec_t* h) { return h ? h->device : -1; }
+int64_t salp_vec_global_step(const salp_vec_t* h) { return h ? h->global_step : 0; }
+
+int salp_vec_reset(salp_vec_t* h, const uint8_t* mask, float* obs, uint32_t flags, void* stream) {
+  if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
+  reset_fn fn = reset_kernel_for(h);
+  if (flags & SALP_DEVICE_PTRS) {
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, mask, obs, 1);
+    HIP_TRY(hipGetLastError());
+    return SALP_OK;
+  }
+  const size_t obs_b = (size_t)h->n * h->obs_dim * sizeof(float);
+  int rc = ensure_stage(h, align_up(obs_b, 256) + align_up((size_t)h->n, 256) + 512);
+  if (rc != SALP_OK) return rc;
+  Bump b{(char*)h->stage, 0};
+  float* d_obs = obs ? b.take<float>((size_t)h->n * h->obs_dim) : nullptr;
+  uint8_t* d_mask = mask ? b.take<uint8_t>((size_t)h->n) : nullptr;
+  if (mask) HIP_TRY(hipMemcpyAsync(d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, (const uint8_t*)d_mask, d_obs, 1);
+  HIP_TRY(hipGetLastError());
+  if (obs) HIP_TRY(hipMemcpyAsync(obs, d_obs, obs_b, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return SALP_OK;
+}
+
+int salp_vec_observe(salp_vec_t* h, float* obs, uint32_t flags, void* stream) {
+  if (!h || !obs) return fail(SALP_ERR_INVALID, "handle/obs is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
+  reset_fn fn = reset_kernel_for(h);
+  if (flags & SALP_DEVICE_PTRS) {
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, (const uint8_t*)nullptr, obs, 0);
+    HIP_TRY(hipGetLastError());
+    return SALP_OK;
+  }
+  const size_t obs_b = (size_t)h->n * h->obs_dim * sizeof(float);
+  int rc = ensure_stage(h, align_up(obs_b, 256) + 512);
+  if (rc != SALP_OK) return rc;
+  float* d_obs = (float*)h->stage;
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, (const uint8_t*)nullptr, d_obs, 0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(obs, d_obs, obs_b, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return SALP_OK;
+}
+
+static int rollout_impl(salp_vec_t* h, const float* act, int32_t H, float* obs, float* reward,
+                        uint8_t* terminated, uint8_t* truncated, float* final_obs, int32_t* info,
+                        float* act_out, uint32_t flags, void* stream) {
+  if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
+  if (H <= 0) return fail(SALP_ERR_INVALID, "horizon must be >= 1");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  IOPtrs io;
+  memset(&io, 0, sizeof(io));
+  io.stats = h->stats_enabled ? h->stats : nullptr;
+  io.global_step = h->global_step;
+  const size_t HN = (size_t)H * (size_t)h->n;
+  if (flags & SALP_DEVICE_PTRS) {
+    io.act = act; io.obs = obs; io.reward = reward; io.terminated = terminated; io.truncated = truncated;
+    io.final_obs = final_obs; io.info = info; io.act_out = act_out;
+    int rc = launch_rollout(h, io, H, st);
+    if (rc == SALP_OK) h->global_step += H;
+    return rc;
+  }
+  // host pointers: stage through device memory, synchronous
+  size_t need = 4096;
+  need += align_up(HN * h->act_dim * sizeof(float), 256) * 2;
+  need += align_up(HN * h->obs_dim * sizeof(float), 256) * (final_obs ? 2 : 1);
+  need += align_up(HN * sizeof(float), 256) + 2 * align_up(HN, 256) + align_up(HN * SALP_INFO_COLS * sizeof(int32_t), 256);
+  int rc = ensure_stage(h, need);
+  if (rc != SALP_OK) return rc;
+  Bump b{(char*)h->stage, 0};
+  float* d_act = act ? b.take<float>(HN * h->act_dim) : nullptr;
+  float* d_aout = (!act && act_out) ? b.take<float>(HN * h->act_dim) : nullptr;
+  float* d_obs = obs ? b.take<float>(HN * h->obs_dim) : nullptr;
+  float* d_fin = final_obs ? b.take<float>(HN * h->obs_dim) : nullptr;
+  float* d_rew = reward ? b.take<float>(HN) : nullptr;
+  uint8_t* d_term = terminated ? b.take<uint8_t>(HN) : nullptr;
+  uint8_t* d_trunc = truncated ? b.take<uint8_t>(HN) : nullptr;
+  int32_t* d_info = info ? b.take<int32_t>(HN * SALP_INFO_COLS) : nullptr;
+  if (act) HIP_TRY(hipMemcpyAsync(d_act, act, HN * h->act_dim * sizeof(float), hipMemcpyHostToDevice, st));
+  if (final_obs) HIP_TRY(hipMemcpyAsync(d_fin, final_obs, HN * h->obs_dim * sizeof(float), hipMemcpyHostToDevice, st));
+  io.act = d_act; io.obs = d_obs; io.reward = d_rew; io.terminated = d_term; io.truncated = d_trunc;
+  io.final_obs = d_fin; io.info = d_info; io.act_out = d_aout;
+  rc = launch_rollout(h, io, H, st);
+  if (rc != SALP_OK) return rc;
+  h->global_step += H;
+  if (obs) HIP_TRY(hipMemcpyAsync(obs, d_obs, HN * h->obs_dim * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (final_obs) HIP_TRY(hipMemcpyAsync(final_obs, d_fin, HN * h->obs_dim * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (reward) HIP_TRY(hipMemcpyAsync(reward, d_rew, HN * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (terminated) HIP_TRY(hipMemcpyAsync(terminated, d_term, HN, hipMemcpyDeviceToHost, st));
+  if (truncated) HIP_TRY(hipMemcpyAsync(truncated, d_trunc, HN, hipMemcpyDeviceToHost, st));
+  if (info) HIP_TRY(hipMemcpyAsync(info, d_info, HN * SALP_INFO_COLS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (d_aout) HIP_TRY(hipMemcpyAsync(act_out, d_aout, HN * h->act_dim * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return SALP_OK;
+}
+
+int salp_vec_step(salp_vec_t* h, const float* act, float* obs, float* reward, uint8_t* terminated,
+                  uint8_t* truncated, float* final_obs, int32_t* info, uint32_t flags, void* stream) {
+  if (!act) return fail(SALP_ERR_INVALID, "act is NULL");
+  return rollout_impl(h, act, 1, obs, reward, terminated, truncated, final_obs, info, nullptr, flags, stream);
+}
+
+int salp_vec_rollout(salp_vec_t* h, const float* act, int32_t horizon, float* obs, float* reward,
+                     uint8_t* terminated, uint8_t* truncated, float* final_obs, float* act_out,
+                     uint32_t flags, void* stream) {
+  return rollout_impl(h, act, horizon, obs, reward, terminated, truncated, final_obs, nullptr, act_out, flags, stream);
+}
+
+int salp_vec_get_state(salp_vec_t* h, double* f64, int32_t* i32, uint32_t flags, void* stream) {
+  if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
+  const size_t fb = (size_t)SALP_F_COUNT(h->F) * h->n * sizeof(double);
+  const size_t ib = (size_t)SALP_I_COUNT * h->n * sizeof(int32_t);
+  if (flags & SALP_DEVICE_PTRS) {
+    hipLaunchKernelGGL(salp_get_state_kernel, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, f64, i32);
+    HIP_TRY(hipGetLastError());
+    return SALP_OK;
+  }
+  int rc = ensure_stage(h, align_up(fb, 256) + align_up(ib, 256) + 512);
+  if (rc != SALP_OK) return rc;
+  Bump b{(char*)h->stage, 0};
+  double* d_f = f64 ? b.take<double>(fb / sizeof(double)) : nullptr;
+  int32_t* d_i = i32 ? b.take<int32_t>(ib / sizeof(int32_t)) : nullptr;
+  hipLaunchKernelGGL(salp_get_state_kernel, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, d_f, d_i);
+  HIP_TRY(hipGetLastError());
+  if (f64) HIP_TRY(hipMemcpyAsync(f64, d_f, fb, hipMemcpyDeviceToHost, st));
+  if (i32) HIP_TRY(hipMemcpyAsync(i32, d_i, ib, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return SALP_OK;
+}
+
+int salp_vec_set_state(salp_vec_t* h, const double* f64, const int32_t* i32, uint32_t flags, void* stream) {
+  if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
+  const size_t fb = (size_t)SALP_F_COUNT(h->F) * h->n * sizeof(double);
+  const size_t ib = (size_t)SALP_I_COUNT * h->n * sizeof(int32_t);
+  if (flags & SALP_DEVICE_PTRS) {
+    hipLaunchKernelGGL(salp_set_state_kernel, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, f64, i32);
+    HIP_TRY(hipGetLastError());
+    return SALP_OK;
+  }
+  int rc = ensure_stage(h, align_up(fb, 256) + align_up(ib, 256) + 512);
+  if (rc != SALP_OK) return rc;
+  Bump b{(char*)h->stage, 0};
+  double* d_f = f64 ? b.take<double>(fb / sizeof(double)) : nullptr;
+  int32_t* d_i = i32 ? b.take<int32_t>(ib / sizeof(int32_t)) : nullptr;
+  if (f64) HIP_TRY(hipMemcpyAsync(d_f, f64, fb, hipMemcpyHostToDevice, st));
+  if (i32) HIP_TRY(hipMemcpyAsync(d_i, i32, ib, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(salp_set_state_kernel, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, (const double*)d_f, (const int32_t*)d_i);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  return SALP_OK;
+}
+
+int salp_vec_get_stats(salp_vec_t* h, salp_stats_t* out) {
+  if (!h || !out) return fail(SALP_ERR_INVALID, "handle/out is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  DevStats host[SALP_STATS_REPLICAS];
+  HIP_TRY(hipMemcpy(host, h->stats, sizeof(host), hipMemcpyDeviceToHost));
+  long long acc[16] = {0};
+  for (int r = 0; r < SALP_STATS_REPLICAS; ++r)
+    for (int k = 0; k < 16; ++k) acc[k] += (long long)host[r].v[k];
+  out->env_steps = acc[ST_STEPS]; out->episodes = acc[ST_EPISODES]; out->terminated = acc[ST_TERM];
+  out->truncated = acc[ST_TRUNC]; out->collisions = acc[ST_COLL]; out->food_collected = acc[ST_FOOD];
+  out->episode_length_sum = acc[ST_EPLEN];
+  out->reward_sum = (double)acc[ST_REWARD] / SALP_FIXED_SCALE;
+  out->episode_return_sum = (double)acc[ST_EPRET] / SALP_FIXED_SCALE;
+  return SALP_OK;
+}
+
+int salp_vec_clear_stats(salp_vec_t* h) {
+  if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(h->stats, 0, SALP_STATS_REPLICAS * sizeof(DevStats)));
+  return SALP_OK;
+}
+
+}  // extern "C"
