@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched SalpSnakeEnv.step hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+N_envs = 262144 per GPU, single_food_long_horizon parameters, random actions resident in HBM,
+the 5000-step rollout run as K fused-rollout launches of `--chunk` steps each (defaults
+K = 20 x 250 = 5000 steps).  One bench "step" = one launch = chunk x N_envs env-steps.
+All inputs (state, actions) are resident in HBM when the timed region starts; every output
+(observations [chunk, N, 24] f32, rewards, terminated, truncated) is written to HBM.
+
+At N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own shard of
+262144 envs (weak scaling) and, per launch, all-gathers the observations the step returned for
+the last step of the chunk over RCCL (`--gather final`, overlapped with the next launch;
+`--gather all` exchanges the whole block, `--gather none` nothing).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the fused rollout kernel against HBM
+(algorithmic bytes per env-step = act 4 + obs 96 + reward 4 + flags 2 + 2*state/H, SURVEY.md
+§8d); `cpu_baseline` times the CPU oracle (oracle/salp_oracle.c) on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def algorithmic_bytes_per_env_step(cfg, horizon: int) -> float:
+    """A + O + 4 + 2 + 2S/H with S = 48 + 8F, O = 4*(10+4K+2), A = 4*act_dim."""
+    S = 48 + 8 * cfg.num_food_items
+    O = 4 * cfg.obs_dim
+    A = 4 * cfg.act_dim
+    return A + O + 4 + 2 + 2.0 * S / horizon
+
+
+def cpu_baseline(cfg, budget_s: float):
+    """Times the CPU oracle on a bounded sample of the same workload (same parameters, random
+    actions, all outputs written).  Rank 0, N = 1 only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the GPU box gives one-GPU jobs a 16-CPU share
+    n, H = 16384, 64
+    orc = ol.OracleVec(cfg, n, seed=0, threads=cores)
+    rng = np.random.default_rng(0)
+    act = rng.uniform(-1, 1, size=(H, n, cfg.act_dim)).astype(np.float32)
+    orc.rollout(act)  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        orc.rollout(act)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 10000:
+            break
+    rate = reps * n * H / el
+    # one-core figure on a smaller sample, for the scalar-port number
+    orc1 = ol.OracleVec(cfg, 2048, seed=0, threads=1)
+    a1 = np.ascontiguousarray(act[:, :2048])
+    orc1.rollout(a1)
+    t1 = time.perf_counter()
+    r1 = 0
+    while time.perf_counter() - t1 < min(3.0, budget_s / 3):
+        orc1.rollout(a1)
+        r1 += 1
+    rate1 = r1 * 2048 * H / (time.perf_counter() - t1)
+    return {
+        "value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": f"C oracle (fp64, libm), OpenMP over envs: {n} envs x {H}-step rollouts x {reps} reps "
+                  f"({el:.1f} s), same env parameters, all outputs written",
+        "one_core_value": rate1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=262144, help="envs per GPU")
+    ap.add_argument("--chunk", type=int, default=250, help="env-steps per fused rollout launch")
+    ap.add_argument("--preset", default="single_food_long_horizon")
+    ap.add_argument("--gather", default="final", choices=["final", "all", "none"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import underwater_swimmer_rl_amd as pkg
+    from underwater_swimmer_rl_amd.vector_env import SalpVectorEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    cfg = pkg.load_env_config(args.preset)
+    n, H, K, W = args.envs, args.chunk, args.steps, args.warmup
+
+    if world > 1:
+        from underwater_swimmer_rl_amd.sharded import ShardedSalpVectorEnv
+        senv = ShardedSalpVectorEnv(cfg, n * world, device=f"cuda:{local_rank}", seed=0)
+        env = senv.engine
+    else:
+        senv = None
+        env = SalpVectorEnv(cfg, n, device=f"cuda:{local_rank}", seed=0, env_index_base=0)
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    act = torch.rand((H, n, cfg.act_dim), generator=gen, device=device, dtype=torch.float32) * 2.0 - 1.0
+
+    def one_launch():
+        if senv is not None:
+            senv.rollout(act, gather=args.gather, async_gather=True)
+        else:
+            env.rollout(act)
+
+    for _ in range(W):
+        one_launch()
+    if senv is not None:
+        senv.wait_gather()
+    env.clear_stats()
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(K):
+        if senv is not None:
+            senv.wait_gather()               # previous chunk's gather must be done before its buffer is reused
+        starts[k].record()
+        if senv is not None:
+            out = senv.engine.rollout(act)
+            ends[k].record()
+            if args.gather == "final":
+                g, work = senv.all_gather("final_obs", out["obs"][-1], async_op=True)
+                senv._pending = work
+            elif args.gather == "all":
+                g, work = senv.all_gather("all_obs", out["obs"].reshape(1, H, n, cfg.obs_dim), async_op=True)
+                senv._pending = work
+        else:
+            env.rollout(act)
+            ends[k].record()
+    if senv is not None:
+        senv.wait_gather()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+
+    el_t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+    elapsed = float(el_t.item())
+    kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+
+    stats = env.stats()
+    assert stats["env_steps"] == n * H * K, (stats["env_steps"], n * H * K)  # nothing skipped in the timed region
+
+    total_env_steps = float(world) * n * H * K
+    value = total_env_steps / elapsed
+    bpe = algorithmic_bytes_per_env_step(cfg, H)
+    achieved_gbs = bpe * n * H / avg_kernel_s / 1e9
+
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.isfile(tp):
+        try:
+            with open(tp) as f:
+                tj = json.load(f)
+            if tj.get("envs") == n and tj.get("chunk") == H and tj.get("preset") == args.preset:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+        "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[2]: N_envs={n}/GPU {args.preset}, {H * K}-step rollout as {K} fused launches of {H} steps, random actions in HBM",
+            "envs_per_gpu": n, "chunk": H, "obs_dim": cfg.obs_dim, "act_dim": cfg.act_dim,
+            "parallelism": f"env-sharded x{world}" + (f", all-gather {args.gather} obs" if world > 1 else ""),
+            "env_steps_per_bench_step": n * H * world,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "salp_rollout_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+            "algorithmic_bytes_per_env_step": bpe, "env_steps_per_launch": n * H,
+        },
+        "episodes_finished": stats["episodes"], "food_collected": stats["food_collected"],
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if senv is not None:
+        senv.close()
+        dist.destroy_process_group()
+    else:
+        env.close()
+
+
+if __name__ == "__main__":
+    main()

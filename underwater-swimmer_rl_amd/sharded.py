@@ -1,0 +1,141 @@
+"""Multi-GPU sharding of the batched simulator: one process per GPU, envs split by index.
+
+The reference is single-process (no distributed code); this is the north_star's
+"sharded across the 8 GPUs of one node by env-index with an RCCL all-gather over xGMI of
+returned observations".  Rank r owns the contiguous block [r*N/G, (r+1)*N/G); the draw streams
+are keyed by GLOBAL env index (include/salp_vec.h "Randomness"), so env i's trajectory is the
+same for every G.  The only exchange is the all-gather of what the step returns
+(`torch.distributed`, backend "nccl" = RCCL on ROCm; "gloo" for the CPU tests); there is no
+reduction on the data path.
+
+`engine_factory(cfg, n_local, seed, env_index_base)` builds the per-rank simulator; the default
+is the HIP `SalpVectorEnv`.  (tests/ inject a CPU checker engine to exercise the sharding and
+gather logic under gloo — the product default never does.)
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .vector_env import SalpVectorEnv, _as_config
+
+
+def _to_tensor(x, device):
+    if isinstance(x, torch.Tensor):
+        return x
+    return torch.from_numpy(np.ascontiguousarray(x)).to(device)
+
+
+class ShardedSalpVectorEnv:
+    def __init__(self, config="single_food", num_envs: int = 8 * 131072, *, process_group=None,
+                 device: Optional[str] = None, seed: int = 0, engine_factory: Optional[Callable] = None,
+                 **overrides):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised (backend 'nccl' on GPUs)")
+        self.pg = process_group
+        self.rank = dist.get_rank(self.pg)
+        self.world = dist.get_world_size(self.pg)
+        if num_envs % self.world != 0:
+            raise ValueError(f"num_envs={num_envs} must be divisible by world size {self.world}")
+        self.cfg = _as_config(config, **overrides)
+        self.num_envs = int(num_envs)
+        self.local_envs = self.num_envs // self.world
+        self.env_index_base = self.rank * self.local_envs
+        if engine_factory is None:
+            dev = device or f"cuda:{torch.cuda.current_device()}"
+            self.engine = SalpVectorEnv(self.cfg, self.local_envs, device=dev, seed=seed,
+                                        env_index_base=self.env_index_base)
+            self.device = self.engine.device
+        else:
+            self.engine = engine_factory(self.cfg, self.local_envs, seed, self.env_index_base)
+            self.device = torch.device("cpu")
+        self.obs_dim, self.act_dim = self.cfg.obs_dim, self.cfg.act_dim
+        self._pending = None
+        self._gbuf = {}
+
+    # ------------------------------------------------------------------ collectives
+    def _out(self, name, local: torch.Tensor):
+        shape = (self.world * local.shape[0],) + tuple(local.shape[1:])
+        b = self._gbuf.get(name)
+        if b is None or tuple(b.shape) != shape or b.dtype != local.dtype:
+            b = torch.empty(shape, dtype=local.dtype, device=local.device)
+            self._gbuf[name] = b
+        return b
+
+    def all_gather(self, name: str, local, async_op: bool = False):
+        """Concatenates every rank's block along dim 0 (rank order = env order)."""
+        local = _to_tensor(local, self.device).contiguous()
+        out = self._out(name, local)
+        try:
+            work = dist.all_gather_into_tensor(out, local, group=self.pg, async_op=async_op)
+        except (RuntimeError, NotImplementedError):
+            chunks = list(out.chunk(self.world, dim=0))
+            work = dist.all_gather(chunks, local, group=self.pg, async_op=async_op)
+        return (out, work) if async_op else out
+
+    def _shard(self, actions, lead):
+        """Accepts global [.., N, A] or local [.., N/G, A] actions; returns this rank's block."""
+        if actions is None:
+            return None
+        n_axis = lead
+        n = actions.shape[n_axis]
+        if n == self.local_envs:
+            return actions
+        if n != self.num_envs:
+            raise ValueError(f"actions have {n} envs; expected {self.num_envs} (global) or {self.local_envs} (local)")
+        sl = [slice(None)] * actions.ndim
+        sl[n_axis] = slice(self.env_index_base, self.env_index_base + self.local_envs)
+        return actions[tuple(sl)]
+
+    # ------------------------------------------------------------------ VectorEnv surface (global views)
+    def reset(self, *, seed=None, options=None):
+        obs, info = self.engine.reset(seed=seed, options=options)
+        return self.all_gather("obs", obs), info
+
+    def step(self, actions):
+        """Every rank returns the full [N, ...] batch (obs, reward, terminated, truncated)."""
+        a = self._shard(actions, 0)
+        obs, rew, term, trunc, info = self.engine.step(a)
+        g_obs = self.all_gather("obs", obs)
+        g_rew = self.all_gather("reward", rew)
+        flags = torch.stack([_to_tensor(term, self.device).to(torch.uint8),
+                             _to_tensor(trunc, self.device).to(torch.uint8)], dim=1)
+        g_flags = self.all_gather("flags", flags)
+        return g_obs, g_rew, g_flags[:, 0].bool(), g_flags[:, 1].bool(), info
+
+    def rollout(self, actions=None, horizon=None, gather: str = "final", async_gather: bool = False):
+        """Local fused rollout of `horizon` steps, then the exchange:
+        gather="final": all-gather the last step's observation [N, obs_dim] (what a centralised
+                        actor needs to continue), "all": the whole [H, N, obs_dim] block,
+                        "none": no exchange (data-parallel learners).
+        Returns (local_outputs, gathered_obs_or_None).  With async_gather the collective overlaps
+        the caller's next launch; call wait_gather() before reading the gathered tensor."""
+        self.wait_gather()
+        a = self._shard(actions, 1)
+        out = self.engine.rollout(a, horizon)
+        g = None
+        if gather == "final":
+            g = self.all_gather("final_obs", out["obs"][-1], async_op=async_gather)
+        elif gather == "all":
+            H = out["obs"].shape[0]
+            # [H, n, D] -> rank-major blocks; viewed back as [G, H, n, D] by the caller
+            g = self.all_gather("all_obs", _to_tensor(out["obs"], self.device).reshape(1, H, self.local_envs, self.obs_dim),
+                                async_op=async_gather)
+        elif gather != "none":
+            raise ValueError("gather must be 'final', 'all' or 'none'")
+        if async_gather and g is not None:
+            self._pending = g[1]
+            g = g[0]
+        return out, g
+
+    def wait_gather(self):
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
+    def close(self):
+        self.wait_gather()
+        self.engine.close()

@@ -1,0 +1,330 @@
+"""Gymnasium-VectorEnv-style host shim over the C ABI (include/salp_vec.h).
+
+`SalpVectorEnv` exposes the surface the reference's consumers use on `SalpSnakeEnv`
+(src/salp/environments/salp_snake_env.py:17) for N environments at once:
+
+    reset(seed=None, options=None) -> (obs, info)                       snake:133-155
+    step(actions) -> (obs, reward, terminated, truncated, info)         snake:157-202
+    num_envs, single_observation_space, single_action_space,
+    observation_space, action_space, close()
+
+Observations / rewards / flags are torch tensors resident on the GPU (`output="torch"`, the
+default) or numpy arrays (`output="numpy"`, host-pointer ABI).  Autoreset is same-step, as in
+gymnasium 0.29's VectorEnv: `info["final_observation"]` holds terminal observations of the
+envs flagged in `info["_final_observation"]`.  Attribute pokes of the reference's eval scripts
+(`env.robot_pos = ...`, eval/collect_navigation_data.py:76-89) map to `get_state()/set_state()`.
+
+`SalpSB3VecEnv` adapts it to stable-baselines3's `VecEnv` duck type (`step_async/step_wait`,
+`dones = terminated | truncated`, `infos[i]["terminal_observation"]`,
+`infos[i]["TimeLimit.truncated"]`), so `SAC("MlpPolicy", env, ...)` (train.py:60-70) can take it.
+
+PyTorch is used for device buffers and streams only; every simulation call goes through the
+C ABI.  If the HIP library or a GPU is missing the constructor raises — there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _capi
+from ._capi import SALP_DEVICE_PTRS, SalpLib
+from .config import SalpSnakeConfig, load_env_config
+from .spaces import batch_space, single_action_space, single_observation_space
+
+ConfigLike = Union[SalpSnakeConfig, str, Dict[str, Any]]
+
+
+def _as_config(cfg: ConfigLike, **overrides) -> SalpSnakeConfig:
+    if isinstance(cfg, SalpSnakeConfig):
+        return cfg
+    if isinstance(cfg, str):
+        return load_env_config(cfg, **overrides)
+    return SalpSnakeConfig(**{**cfg, **overrides})
+
+
+class SalpVectorEnv:
+    metadata = {"render_modes": [], "autoreset_mode": "same-step"}
+
+    def __init__(self, config: ConfigLike = "single_food", num_envs: int = 4096, device: Union[str, int] = "cuda:0",
+                 seed: int = 0, env_index_base: int = 0, output: str = "torch", **overrides):
+        self.cfg = _as_config(config, **overrides)
+        self.num_envs = int(num_envs)
+        self.output = output
+        if output not in ("torch", "numpy"):
+            raise ValueError("output must be 'torch' or 'numpy'")
+        self._device_index = int(str(device).split(":")[1]) if isinstance(device, str) and ":" in str(device) else (
+            int(device) if not isinstance(device, str) else 0)
+        self.seed_value = int(seed)
+        self.env_index_base = int(env_index_base)
+        self._lib = SalpLib(self.cfg, self.num_envs, self._device_index, self.seed_value, self.env_index_base)
+        self.obs_dim, self.act_dim = self._lib.obs_dim, self._lib.act_dim
+        self.single_observation_space = single_observation_space(self.cfg)
+        self.single_action_space = single_action_space(self.cfg)
+        self.observation_space = batch_space(self.single_observation_space, self.num_envs)
+        self.action_space = batch_space(self.single_action_space, self.num_envs)
+        self._torch = None
+        if output == "torch":
+            import torch
+            if not torch.cuda.is_available():
+                raise _capi.SalpError("output='torch' needs a ROCm GPU visible to PyTorch")
+            self._torch = torch
+            self.device = torch.device("cuda", self._device_index)
+        else:
+            self.device = None
+        self._bufs: Dict[str, Any] = {}
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, shape, dtype):
+        b = self._bufs.get(name)
+        if b is None or tuple(b.shape) != tuple(shape):
+            if self._torch is not None:
+                td = {np.float32: self._torch.float32, np.uint8: self._torch.uint8, np.int32: self._torch.int32,
+                      np.float64: self._torch.float64}[dtype]
+                b = self._torch.empty(shape, dtype=td, device=self.device)
+            else:
+                b = np.empty(shape, dtype=dtype)
+            self._bufs[name] = b
+        return b
+
+    @property
+    def _flags(self):
+        return SALP_DEVICE_PTRS if self._torch is not None else 0
+
+    @property
+    def _stream(self):
+        if self._torch is None:
+            return 0
+        return int(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _actions_in(self, actions, lead_shape):
+        shape = tuple(lead_shape) + (self.act_dim,)
+        if self._torch is not None:
+            t = self._torch
+            if not isinstance(actions, t.Tensor):
+                actions = t.as_tensor(np.asarray(actions, dtype=np.float32))
+            a = actions.to(device=self.device, dtype=t.float32).reshape(shape).contiguous()
+            return a
+        return np.ascontiguousarray(np.asarray(actions, dtype=np.float32).reshape(shape))
+
+    # ------------------------------------------------------------------ Gymnasium surface
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask=None):
+        """Resets every env (or those in `mask`).  `seed` re-keys the draw streams (the reference's
+        reset(seed) only seeds gymnasium's unused np_random, snake:136)."""
+        if seed is not None and int(seed) != self.seed_value:
+            self._lib.close()
+            self.seed_value = int(seed)
+            self._lib = SalpLib(self.cfg, self.num_envs, self._device_index, self.seed_value, self.env_index_base)
+            obs = self._buf("obs", (self.num_envs, self.obs_dim), np.float32)
+            self._lib.observe(obs, self._flags, self._stream)
+            return obs, {}
+        obs = self._buf("obs", (self.num_envs, self.obs_dim), np.float32)
+        m = None
+        if mask is not None:
+            if self._torch is not None:
+                m = self._torch.as_tensor(mask).to(device=self.device, dtype=self._torch.uint8).contiguous()
+            else:
+                m = np.ascontiguousarray(np.asarray(mask, dtype=np.uint8))
+        self._lib.reset(m, obs, self._flags, self._stream)
+        return obs, {}
+
+    def step(self, actions, want_final_observation: bool = True):
+        n = self.num_envs
+        a = self._actions_in(actions, (n,))
+        obs = self._buf("obs", (n, self.obs_dim), np.float32)
+        rew = self._buf("reward", (n,), np.float32)
+        term = self._buf("terminated", (n,), np.uint8)
+        trunc = self._buf("truncated", (n,), np.uint8)
+        info_i = self._buf("info", (n, _capi.INFO_COLS), np.int32)
+        fin = self._buf("final_obs", (n, self.obs_dim), np.float32) if want_final_observation else None
+        self._lib.step(a, obs, rew, term, trunc, fin, info_i, self._flags, self._stream)
+        if self._torch is not None:
+            terminated, truncated = term.bool(), trunc.bool()
+        else:
+            terminated, truncated = term.astype(bool), trunc.astype(bool)
+        info = {
+            "food_collected": info_i[:, 0], "steps_since_food": info_i[:, 1], "collision": info_i[:, 2],
+            "score": info_i[:, 0] * float(self.cfg.food_reward),
+        }
+        if fin is not None:
+            info["final_observation"] = fin
+            info["_final_observation"] = terminated | truncated
+        return obs, rew, terminated, truncated, info
+
+    def rollout(self, actions=None, horizon: Optional[int] = None, want_obs: bool = True,
+                want_final_observation: bool = False, out: Optional[dict] = None) -> dict:
+        """`horizon` steps in one kernel launch.  actions: [H, N, act_dim] or None (device-generated)."""
+        n = self.num_envs
+        if actions is not None:
+            if hasattr(actions, "shape"):
+                horizon = int(actions.shape[0])
+            else:
+                horizon = len(actions)
+            a = self._actions_in(actions, (horizon, n))
+            aout = None
+        else:
+            if horizon is None:
+                raise ValueError("horizon is required when actions is None")
+            a = None
+            aout = self._buf("r_act", (horizon, n, self.act_dim), np.float32)
+        H = int(horizon)
+        out = out or {}
+        obs = out.get("obs") if "obs" in out else (self._buf("r_obs", (H, n, self.obs_dim), np.float32) if want_obs else None)
+        rew = out.get("reward") if "reward" in out else self._buf("r_reward", (H, n), np.float32)
+        term = out.get("terminated") if "terminated" in out else self._buf("r_term", (H, n), np.uint8)
+        trunc = out.get("truncated") if "truncated" in out else self._buf("r_trunc", (H, n), np.uint8)
+        fin = self._buf("r_final", (H, n, self.obs_dim), np.float32) if want_final_observation else None
+        self._lib.rollout(a, H, obs, rew, term, trunc, fin, aout, self._flags, self._stream)
+        return dict(obs=obs, reward=rew, terminated=term, truncated=trunc, final_obs=fin,
+                    actions=a if a is not None else aout)
+
+    def observe(self):
+        obs = self._buf("obs", (self.num_envs, self.obs_dim), np.float32)
+        self._lib.observe(obs, self._flags, self._stream)
+        return obs
+
+    def close(self):
+        self._lib.close()
+        self._bufs.clear()
+
+    # ------------------------------------------------------------------ state access
+    def get_state(self):
+        """(f64 [SALP_F_COUNT(F), N], i32 [SALP_I_COUNT, N]) host numpy arrays; rows in _capi.F_* / I_*."""
+        F = self.cfg.num_food_items
+        f64 = np.empty((_capi.F_FOOD0 + 2 * F, self.num_envs), np.float64)
+        i32 = np.empty((_capi.I_COUNT, self.num_envs), np.int32)
+        if self._torch is not None:
+            self._torch.cuda.current_stream(self.device).synchronize()
+        self._lib.get_state(f64, i32, 0, 0)
+        return f64, i32
+
+    def set_state(self, f64=None, i32=None):
+        f = None if f64 is None else np.ascontiguousarray(f64, dtype=np.float64)
+        i = None if i32 is None else np.ascontiguousarray(i32, dtype=np.int32)
+        if self._torch is not None:
+            self._torch.cuda.current_stream(self.device).synchronize()
+        self._lib.set_state(f, i, 0, 0)
+
+    # the attributes the reference's callers read/poke, as whole-batch arrays
+    @property
+    def robot_pos(self):
+        f, _ = self.get_state()
+        return np.stack([f[_capi.F_X], f[_capi.F_Y]], axis=1)
+
+    @property
+    def robot_velocity(self):
+        f, _ = self.get_state()
+        return np.stack([f[_capi.F_VX], f[_capi.F_VY]], axis=1)
+
+    @property
+    def robot_angle(self):
+        return self.get_state()[0][_capi.F_THETA]
+
+    @property
+    def food_positions(self):
+        f, _ = self.get_state()
+        F = self.cfg.num_food_items
+        return np.stack([f[_capi.F_FOOD0:_capi.F_FOOD0 + F].T, f[_capi.F_FOOD0 + F:_capi.F_FOOD0 + 2 * F].T], axis=2)
+
+    def stats(self) -> dict:
+        return self._lib.stats()
+
+    def clear_stats(self):
+        self._lib.clear_stats()
+
+    @property
+    def global_step(self) -> int:
+        return self._lib.global_step
+
+
+class _LazyInfos(Sequence):
+    """SB3 wants `list[dict]` per step; at thousands of envs that list is the bottleneck, so the
+    dicts are materialised on access."""
+
+    def __init__(self, n, food, ssf, coll, dones, truncs, terminal_obs, food_reward):
+        self._n, self._food, self._ssf, self._coll = n, food, ssf, coll
+        self._dones, self._truncs, self._tobs, self._fr = dones, truncs, terminal_obs, food_reward
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        d = {"food_collected": int(self._food[i]), "steps_since_food": int(self._ssf[i]),
+             "collision": bool(self._coll[i]), "score": float(self._food[i]) * self._fr,
+             "TimeLimit.truncated": bool(self._truncs[i])}
+        if self._dones[i]:
+            d["terminal_observation"] = self._tobs[i]
+        return d
+
+
+class SalpSB3VecEnv:
+    """stable-baselines3 `VecEnv` duck type over SalpVectorEnv (numpy in / numpy out)."""
+
+    def __init__(self, config: ConfigLike = "single_food", num_envs: int = 8, device: Union[str, int] = 0,
+                 seed: int = 0, **overrides):
+        self.venv = SalpVectorEnv(config, num_envs, device=device, seed=seed, output="numpy", **overrides)
+        self.num_envs = self.venv.num_envs
+        self.observation_space = self.venv.single_observation_space
+        self.action_space = self.venv.single_action_space
+        self.render_mode = None
+        self._actions = None
+
+    def reset(self):
+        obs, _ = self.venv.reset()
+        return obs.copy()
+
+    def step_async(self, actions):
+        self._actions = np.asarray(actions, dtype=np.float32)
+
+    def step_wait(self):
+        obs, rew, term, trunc, info = self.venv.step(self._actions)
+        dones = term | trunc
+        infos = _LazyInfos(self.num_envs, info["food_collected"].copy(), info["steps_since_food"].copy(),
+                           info["collision"].copy(), dones, trunc & ~term, info["final_observation"].copy(),
+                           float(self.venv.cfg.food_reward))
+        return obs.copy(), rew.copy(), dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.venv.close()
+
+    def seed(self, seed=None):
+        if seed is not None:
+            self.venv.reset(seed=seed)
+        return [seed] * self.num_envs
+
+    def _indices(self, indices):
+        if indices is None:
+            return range(self.num_envs)
+        if isinstance(indices, int):
+            return [indices]
+        return indices
+
+    def get_attr(self, attr_name, indices=None):
+        idx = list(self._indices(indices))
+        if hasattr(self.venv.cfg, attr_name):
+            return [getattr(self.venv.cfg, attr_name)] * len(idx)
+        v = getattr(self.venv, attr_name)
+        return [v[i] for i in idx]
+
+    def set_attr(self, attr_name, value, indices=None):
+        raise AttributeError(f"{attr_name}: parameters are fixed at construction; state goes through set_state()")
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        raise AttributeError(f"env_method({method_name}) is not supported by the batched simulator")
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * len(list(self._indices(indices)))
+
+    def get_images(self):
+        return [None] * self.num_envs
+
+    def render(self, mode=None):
+        return None
