@@ -56,6 +56,26 @@ struct DevParams {
   int64_t pitch;            // row pitch (elements) of the SoA state blocks
 };
 
+// Compile-time image of the reference's hard-coded constants (legacy:32-53, snake:53-54, 800x600).
+// Kernels instantiated with STD = true read these literals (rematerialisable scalar immediates: no
+// SGPR pressure, no spills); any other configuration takes the values from DevParams.
+struct StdConsts {
+  static constexpr double W = 800.0, H = 600.0, half_W = 400.0, half_H = 300.0;
+  static constexpr double margin = 50.0, wall_hi_x = 750.0, wall_hi_y = 550.0;
+  static constexpr double R = 30.0, a_rest = 39.0, b_rest = 24.0, ab_full = 33.0;
+  static constexpr double da_inh = -6.0, db_inh = 9.0, da_exh = 6.0, db_exh = -9.0;
+  static constexpr double max_nozzle = 1.0471975511965976, nozzle_rate = 0.05, thrust_force = 100.0;
+  static constexpr double drag = 0.98, ang_drag = 0.95, exhale_dur_d = 150.0;
+  static constexpr double food_radius = 15.0, min_food_dist2 = 6400.0;
+  static constexpr double food_xlo = 65.0, food_xspan = 670.0, food_ylo = 65.0, food_yspan = 470.0;
+  static constexpr double inv_W = 1.0 / 800.0, inv_H = 1.0 / 600.0, inv_pi = 1.0 / 3.141592653589793;
+  static constexpr double inv_R = 1.0 / 30.0, inv_max_nozzle = 1.0 / 1.0471975511965976;
+  static constexpr float inv_diag = 1.0e-3f;
+  static constexpr int inhale_dur = 120, exhale_dur = 150, cycle_len = 330;
+};
+// CV(name): the constant `name` for this instantiation
+#define CV(name) (STD ? StdConsts::name : P.name)
+
 // SoA state rows (device layout; distinct from the public snapshot layout)
 enum { SF_X = 0, SF_Y, SF_VX, SF_VY, SF_TH, SF_OM, SF_NOZ, SF_WATER, SF_EPRET, SF_FOOD0 };
 enum { SI_PACKED = 0, SI_SSF, SI_FC, SI_RNG, SI_EPLEN, SI_COUNT };
@@ -159,33 +179,122 @@ __device__ __forceinline__ U4 next_block(Env<FMAX>& e, const DevParams& P, uint6
   return w;
 }
 
-template <int FMAX>
+template <int FMAX, bool STD>
 __device__ __forceinline__ void draw_xy(Env<FMAX>& e, const DevParams& P, uint64_t genv, double& x, double& y) {
   const U4 w = next_block(e, P, genv);
-  x = P.food_xlo + P.food_xspan * u53(w.x, w.y);
-  y = P.food_ylo + P.food_yspan * u53(w.z, w.w);
+  x = CV(food_xlo) + CV(food_xspan) * u53(w.x, w.y);
+  y = CV(food_ylo) + CV(food_yspan) * u53(w.z, w.w);
+}
+
+// ------------------------------------------------------------------ fp64 trigonometry
+// sin and cos of |x| <= ~6 (thrust angles are bounded by pi + pi/3 + pi/2): Cody-Waite reduction by
+// pi/2 in two pieces (k <= 4, so k*PIO2_1 is exact) and the fdlibm kernel polynomials on
+// [-pi/4, pi/4].  <= 1 ulp-class accuracy; explicit fma() is allowed here because these values
+// have no bit-exact counterpart on the CPU anyway (glibc's sin/cos are a different algorithm).
+__device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
+  const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+  double r = fma(-fn, 1.57079632673412561417e+00, x);
+  r = fma(-fn, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  // kernel sin
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  const double v = z * r;
+  const double sr = fma(v, fma(z, ps, -1.66666666666666324348e-01), r);
+  // kernel cos
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+  const int q = (int)fn & 3;
+  const double s0 = (q & 1) ? cr : sr;
+  const double c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// sin(x) for |x| <= pi/3 (the nozzle angle): odd Taylor polynomial to x^21, error < 2e-22.
+__device__ __forceinline__ double sin_nozzle(double x) {
+  const double z = x * x;
+  double p = fma(z, 1.9572941063391263e-20, -8.2206352466243295e-18);   // 1/21!, -1/19!
+  p = fma(z, p, 2.8114572543455206e-15);    //  1/17!
+  p = fma(z, p, -7.6471637318198164e-13);   // -1/15!
+  p = fma(z, p, 1.6059043836821613e-10);    //  1/13!
+  p = fma(z, p, -2.5052108385441720e-08);   // -1/11!
+  p = fma(z, p, 2.7557319223985893e-06);    //  1/9!
+  p = fma(z, p, -1.9841269841269841e-04);   // -1/7!
+  p = fma(z, p, 8.3333333333333332e-03);    //  1/5!
+  p = fma(z, p, -1.6666666666666666e-01);   // -1/3!
+  return fma(x * z, p, x);
 }
 
 // Ellipse semi-axes implied by the post-step state (see SALP_I_SHAPE_HOLD in salp_vec.h).
+template <bool STD>
 __device__ __forceinline__ void shape_of(const DevParams& P, uint32_t packed, double water, double& a, double& b) {
   const int phase = bw_phase(packed), timer = bw_timer(packed), dur = bw_dur(packed), hold = bw_hold(packed);
-  if (hold == 7) { a = P.R; b = P.R; return; }
+  if (hold == 7) { a = CV(R); b = CV(R); return; }
   if (hold != 0) {
-    const double p = (double)hold / (double)P.inhale_dur;
-    a = P.a_rest + P.da_inh * p; b = P.b_rest + P.db_inh * p; return;
+    const double p = (double)hold / (double)CV(inhale_dur);
+    a = CV(a_rest) + CV(da_inh) * p; b = CV(b_rest) + CV(db_inh) * p; return;
   }
-  if (phase == 0) { a = P.a_rest; b = P.b_rest; }
-  else if (phase == 1 || timer == 0) { a = P.a_rest + P.da_inh * water; b = P.b_rest + P.db_inh * water; }
+  if (phase == 0) { a = CV(a_rest); b = CV(b_rest); }
+  else if (phase == 1 || timer == 0) { a = CV(a_rest) + CV(da_inh) * water; b = CV(b_rest) + CV(db_inh) * water; }
   else {
     const double p = (double)timer / (double)dur;
-    a = P.ab_full + P.da_exh * p; b = P.ab_full + P.db_exh * p;
+    a = CV(ab_full) + CV(da_exh) * p; b = CV(ab_full) + CV(db_exh) * p;
   }
 }
 
-// snake:92-131 _generate_food_positions + legacy:95-117 / snake:133-151 reset
-template <int FMAX>
-__device__ __forceinline__ void reset_env(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
-  e.x = P.half_W; e.y = P.half_H; e.vx = 0.0; e.vy = 0.0; e.th = 0.0; e.om = 0.0;
+// Food placement, shared by reset (snake:92-131 _generate_food_positions) and respawn
+// (snake:232-276 _respawn_food).  Both are the same rejection sampler: draw (x, y); reject if within
+// min_food_distance of a live food or of the robot — at reset the robot sits at the tank centre,
+// which is the point snake:115 tests against — and after `limit` rejections (100 at reset, 50 at
+// respawn) accept the next draw unconditionally.  The accepted point fills the first empty slot
+// (at reset slots fill in order, snake:120; at respawn snake:261-264).  `todo` = foods still to place.
+template <int FMAX, bool STD>
+__device__ __forceinline__ void place_food(Env<FMAX>& e, const DevParams& P, uint64_t genv, int todo, int limit) {
+  int attempts = 0;
+#pragma unroll 1
+  while (__any(todo > 0)) {
+    if (todo > 0) {
+      double x, y;
+      draw_xy<FMAX, STD>(e, P, genv, x, y);
+      bool valid = true;
+      {
+        const double dx = x - e.x, dy = y - e.y;
+        if (dx * dx + dy * dy < CV(min_food_dist2)) valid = false;
+      }
+#pragma unroll
+      for (int k = 0; k < FMAX; ++k) {
+        const double dx = x - e.fx[k], dy = y - e.fy[k];
+        if (dx * dx + dy * dy < CV(min_food_dist2)) valid = false;   // NaN (empty) slots never reject
+      }
+      if (valid || attempts >= limit) {
+        bool put = false;
+#pragma unroll
+        for (int k = 0; k < FMAX; ++k) {
+          if (!put && k < P.F && is_none(e.fx[k])) { e.fx[k] = x; e.fy[k] = y; put = true; }
+        }
+        todo -= 1;
+        attempts = 0;
+      } else {
+        attempts += 1;
+      }
+    }
+  }
+}
+
+// legacy:95-117 reset + snake:133-149 (pose, breathing, counters, episode food count); the food
+// itself is placed by place_food(e, ..., todo = return value, limit = 100).
+template <int FMAX, bool STD>
+__device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
+  e.x = CV(half_W); e.y = CV(half_H); e.vx = 0.0; e.vy = 0.0; e.th = 0.0; e.om = 0.0;
   e.noz = 0.0; e.water = 0.0; e.epret = 0.0;
   e.packed = pack_breath(0, 0, bw_dur(e.packed), 7);
   e.ssf = 0; e.fc = 0; e.eplen = 0;
@@ -198,103 +307,103 @@ __device__ __forceinline__ void reset_env(Env<FMAX>& e, const DevParams& P, uint
   }
 #pragma unroll
   for (int k = 0; k < FMAX; ++k) { e.fx[k] = __builtin_nan(""); e.fy[k] = __builtin_nan(""); }
-#pragma unroll 1
-  for (int f = 0; f < nf; ++f) {
-    double x = 0.0, y = 0.0;
-    int attempts = 0;
-    bool placed = false;
-#pragma unroll 1
-    while (attempts < 100) {
-      draw_xy(e, P, genv, x, y);
-      bool valid = true;
-#pragma unroll
-      for (int k = 0; k < FMAX; ++k) {   // earlier foods occupy slots 0..f-1; the rest are NaN
-        const double dx = x - e.fx[k], dy = y - e.fy[k];
-        if (dx * dx + dy * dy < P.min_food_dist2) valid = false;
-      }
-      {
-        const double dx = x - P.half_W, dy = y - P.half_H;
-        if (dx * dx + dy * dy < P.min_food_dist2) valid = false;
-      }
-      if (valid) { placed = true; break; }
-      ++attempts;
-    }
-    if (!placed) draw_xy(e, P, genv, x, y);
-#pragma unroll
-    for (int k = 0; k < FMAX; ++k) if (k == f) { e.fx[k] = x; e.fy[k] = y; }
-  }
+  return nf;
 }
 
-// snake:232-276 _respawn_food
-template <int FMAX>
-__device__ __forceinline__ void respawn_food(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
-  double x = 0.0, y = 0.0;
-  int attempts = 0;
-  bool placed = false;
-#pragma unroll 1
-  while (attempts < 50) {
-    draw_xy(e, P, genv, x, y);
-    bool valid = true;
-    {
-      const double dx = x - e.x, dy = y - e.y;
-      if (dx * dx + dy * dy < P.min_food_dist2) valid = false;
-    }
-#pragma unroll
-    for (int k = 0; k < FMAX; ++k) {
-      const double dx = x - e.fx[k], dy = y - e.fy[k];
-      if (dx * dx + dy * dy < P.min_food_dist2) valid = false;
-    }
-    if (valid) { placed = true; break; }
-    ++attempts;
-  }
-  if (!placed) draw_xy(e, P, genv, x, y);
-  bool done = false;
-#pragma unroll
-  for (int k = 0; k < FMAX; ++k) {
-    if (!done && k < P.F && is_none(e.fx[k])) { e.fx[k] = x; e.fy[k] = y; done = true; }
-  }
-}
-
-// legacy:261-314 _apply_jet_thrust (water is the value BEFORE this step's decay)
-template <int FMAX>
+// legacy:261-314 _apply_jet_thrust (water is the value BEFORE this step's decay).
+// The reference evaluates cos/sin at three angles: phi, fl(phi + pi/2) and fl(phi + jitter).  One
+// sincos(phi) serves all three: the side angle is a quarter turn plus the (exactly recovered)
+// rounding error of the addition, the jitter angle a rotation by |D| <= 0.025 (short series).
+template <int FMAX, bool STD>
 __device__ __forceinline__ void apply_jet_thrust(Env<FMAX>& e, const DevParams& P, uint64_t genv, double r) {
-  const double T = (P.thrust_force * e.water) * 0.4;
+  const double T = (CV(thrust_force) * e.water) * 0.4;
   const double phi = e.th - e.noz;
   double s, c;
-  sincos(phi, &s, &c);
+  sincos_small(phi, s, c);
   e.vx = e.vx + (c * T) * 0.012;
   e.vy = e.vy + (s * T) * 0.012;
   const double nn = -e.noz;
   const double primary = (nn * T) * 0.0002;
   const double arm = r * 0.7;
-  const double perp = T * sin(nn);
+  const double perp = T * sin_nozzle(nn);
   const double moment = (perp * arm) * 0.00005;
   const double shape = ((nn * T) * e.water) * 0.00003;
   e.om = e.om + ((primary + moment) + shape);
-  const double side = phi + SALP_PIO2;
-  const double S = (T * fabs(e.noz)) * 0.3;
-  double ss, sc;
-  sincos(side, &ss, &sc);
-  e.vx = e.vx + (sc * S) * 0.008;
-  e.vy = e.vy + (ss * S) * 0.008;
-  const U4 w = next_block(e, P, genv);
-  const double u = u53(w.x, w.y);
-  const double na = phi + (u - 0.5) * 0.05;
-  const double nf = T * 0.04;
-  double ns, nc;
-  sincos(na, &ns, &nc);
-  e.vx = e.vx + (nc * nf) * 0.002;
-  e.vy = e.vy + (ns * nf) * 0.002;
+  {  // side thrust at fl(phi + fl(pi/2)) = phi + pi/2 + dl,  dl = (fl(pi/2) - pi/2) - err
+    const double side = phi + SALP_PIO2;
+    const double bb = side - phi;
+    const double err = (phi - (side - bb)) + (SALP_PIO2 - bb);   // phi + PIO2 = side + err exactly
+    const double dl = -6.123233995736766e-17 - err;
+    const double sc = -fma(dl, c, s);     // cos(side) = -sin(phi + dl)
+    const double ss = fma(-dl, s, c);     // sin(side) =  cos(phi + dl)
+    const double S = (T * fabs(e.noz)) * 0.3;
+    e.vx = e.vx + (sc * S) * 0.008;
+    e.vy = e.vy + (ss * S) * 0.008;
+  }
+  {  // jitter at fl(phi + d), d = fl((u - 0.5) * 0.05)
+    const U4 w = next_block(e, P, genv);
+    const double u = u53(w.x, w.y);
+    const double d = (u - 0.5) * 0.05;
+    const double na = phi + d;
+    const double bb = na - phi;
+    const double err = (phi - (na - bb)) + (d - bb);
+    const double D = d - err;             // na = phi + D (to ~1e-18)
+    const double z = D * D;
+    double sp = fma(z, 2.7557319223985893e-06, -1.9841269841269841e-04);
+    sp = fma(z, sp, 8.3333333333333332e-03);
+    sp = fma(z, sp, -1.6666666666666666e-01);
+    const double sD = fma(D * z, sp, D);
+    double cp = fma(z, 2.4801587301587302e-05, -1.3888888888888889e-03);
+    cp = fma(z, cp, 4.1666666666666664e-02);
+    cp = fma(z, cp, -0.5);
+    const double cD = fma(z, cp, 1.0);
+    const double nc = c * cD - s * sD;
+    const double ns = s * cD + c * sD;
+    const double nf = T * 0.04;
+    e.vx = e.vx + (nc * nf) * 0.002;
+    e.vy = e.vy + (ns * nf) * 0.002;
+  }
+}
+
+// Geometry of the nearest live food (first minimum, snake:350-364) in fp64 state terms.
+struct Nearest {
+  double dx, dy, d2;
+  bool any;
+};
+template <int FMAX>
+__device__ __forceinline__ Nearest nearest_food(const Env<FMAX>& e) {
+  Nearest g;
+  g.dx = 0.0; g.dy = 0.0; g.d2 = 0.0; g.any = false;
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) {
+    const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
+    const double d2 = dx * dx + dy * dy;
+    if (!is_none(e.fx[k]) && (!g.any || d2 < g.d2)) { g.any = true; g.d2 = d2; g.dx = dx; g.dy = dy; }
+  }
+  return g;
+}
+
+// Heading of the nearest food relative to the body axis, wrapped to [-pi, pi] (fp32).
+__device__ __forceinline__ float relative_heading(float dy, float dx, float th) {
+  float rel = atan2f(dy, dx) - th;
+  if (rel > 3.14159265358979f) rel -= 6.28318530717959f;
+  if (rel < -3.14159265358979f) rel += 6.28318530717959f;
+  return rel;
 }
 
 struct StepOut {
-  double rmax;   // max(ellipse_a, ellipse_b) of this step
+  double rmax;    // max(ellipse_a, ellipse_b) of this step
   float reward;
+  float rel;      // relative heading of the nearest food used by the reward (valid if rel_valid)
+  bool rel_valid; // the reward evaluated `rel` for the food set that observe() will also see
   bool terminated, truncated, collision, collected;
 };
 
 // One reference step (legacy:119-156 under snake:157-189), without autoreset / observation.
-template <int FMAX, bool FORCED>
+// The respawn of a collected food (snake:179-180) is left to the caller — place_food(todo = 1,
+// limit = 50) when o.collected && P.respawn, BEFORE any autoreset so the draw order of the
+// reference is kept.  (The all-collected termination test only applies when !P.respawn.)
+template <int FMAX, bool FORCED, bool STD>
 __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, uint64_t genv, float a0, float a1) {
   int phase = bw_phase(e.packed), timer = bw_timer(e.packed), dur = bw_dur(e.packed);
   // legacy:121-135
@@ -302,20 +411,20 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
   bool inhaling;
   if (FORCED) {
     nd = (double)a0;
-    const int tm = (P.cycle_len > 255) ? timer : (timer % P.cycle_len);
-    inhaling = tm < P.inhale_dur;
+    const int tm = (CV(cycle_len) > 255) ? timer : (timer % CV(cycle_len));
+    inhaling = tm < CV(inhale_dur);
   } else {
     inhaling = a0 > 0.5f;
     nd = (double)a1;
   }
-  const double target = nd * P.max_nozzle;
+  const double target = nd * CV(max_nozzle);
   // legacy:169-182 _update_nozzle
   {
     const double diff = target - e.noz;
     double nz;
-    if (fabs(diff) > P.nozzle_rate) nz = (diff > 0) ? (e.noz + P.nozzle_rate) : (e.noz - P.nozzle_rate);
+    if (fabs(diff) > CV(nozzle_rate)) nz = (diff > 0) ? (e.noz + CV(nozzle_rate)) : (e.noz - CV(nozzle_rate));
     else nz = target;
-    e.noz = pymax(-P.max_nozzle, pymin(P.max_nozzle, nz));
+    e.noz = pymax(-CV(max_nozzle), pymin(CV(max_nozzle), nz));
   }
   // legacy:184-259 _update_breathing_cycle
   double a, b;
@@ -324,21 +433,21 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
   double water_next = e.water;
   {
     const int tnew = timer + 1;
-    const double den = (phase == 2) ? (double)dur : (double)P.inhale_dur;
+    const double den = (phase == 2) ? (double)dur : (double)CV(inhale_dur);
     const double p = (double)tnew / den;
     if (phase == 0) {
-      a = P.a_rest; b = P.b_rest;
+      a = CV(a_rest); b = CV(b_rest);
       if (inhaling) { phase = 1; timer = 0; }
     } else if (phase == 1) {
-      if (inhaling && timer < P.inhale_dur) {
+      if (inhaling && timer < CV(inhale_dur)) {
         timer = tnew;
-        a = P.a_rest + P.da_inh * p; b = P.b_rest + P.db_inh * p;
+        a = CV(a_rest) + CV(da_inh) * p; b = CV(b_rest) + CV(db_inh) * p;
         water_next = p;
       } else {
-        a = P.a_rest + P.da_inh * e.water; b = P.b_rest + P.db_inh * e.water;  // unchanged ellipse
+        a = CV(a_rest) + CV(da_inh) * e.water; b = CV(b_rest) + CV(db_inh) * e.water;  // unchanged ellipse
         if (e.water > 0.05) {
           phase = 2; timer = 0;
-          dur = (int)(P.exhale_dur_d * pymax(e.water, 0.3));
+          dur = (int)(CV(exhale_dur_d) * pymax(e.water, 0.3));
         } else {
           hold = (timer >= 1 && timer <= 6) ? timer : 0;
           phase = 0; timer = 0; water_next = 0.0;
@@ -347,30 +456,30 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
     } else {
       if (p <= 1.0) {
         timer = tnew;
-        a = P.ab_full + P.da_exh * p; b = P.ab_full + P.db_exh * p;
+        a = CV(ab_full) + CV(da_exh) * p; b = CV(ab_full) + CV(db_exh) * p;
         thrust = (0.1 <= p) && (p <= 0.5);
         const double v = e.water * (1.0 - p);
         water_next = (v > 0) ? v : 0.0;
       } else {
-        a = P.ab_full + P.da_exh * 1.0; b = P.ab_full + P.db_exh * 1.0;  // ellipse of the last exhale step
+        a = CV(ab_full) + CV(da_exh) * 1.0; b = CV(ab_full) + CV(db_exh) * 1.0;  // ellipse of the last exhale step
         phase = 0; timer = 0; water_next = 0.0;
       }
     }
   }
   const double r = pymax(a, b);
-  if (thrust) apply_jet_thrust(e, P, genv, r);
+  if (thrust) apply_jet_thrust<FMAX, STD>(e, P, genv, r);
   e.water = water_next;
   e.packed = pack_breath(phase, timer, dur, hold);
   // legacy:316-352 _update_physics
-  e.vx = e.vx * P.drag; e.vy = e.vy * P.drag; e.om = e.om * P.ang_drag;
+  e.vx = e.vx * CV(drag); e.vy = e.vy * CV(drag); e.om = e.om * CV(ang_drag);
   e.x = e.x + e.vx; e.y = e.y + e.vy; e.th = e.th + e.om;
 #pragma unroll 1
   for (int it = 0; it < 8 && e.th > SALP_PI; ++it) e.th -= SALP_2PI;
 #pragma unroll 1
   for (int it = 0; it < 8 && e.th < -SALP_PI; ++it) e.th += SALP_2PI;
   {
-    const double m = P.margin + r;
-    const double hx = P.W - m, hy = P.H - m;
+    const double m = CV(margin) + r;
+    const double hx = CV(W) - m, hy = CV(H) - m;
     if (e.x < m) { e.x = m; e.vx = fabs(e.vx) * 0.4; e.om = e.om * 0.7; }
     else if (e.x > hx) { e.x = hx; e.vx = -fabs(e.vx) * 0.4; e.om = e.om * 0.7; }
     if (e.y < m) { e.y = m; e.vy = fabs(e.vy) * 0.4; e.om = e.om * 0.7; }
@@ -381,7 +490,7 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
   // snake:204-217 _check_food_collection (first live food inside the capture radius)
   o.collected = false;
   {
-    const double cr = r + P.food_radius;
+    const double cr = r + CV(food_radius);
     const double cr2 = cr * cr;
 #pragma unroll
     for (int k = 0; k < FMAX; ++k) {
@@ -392,7 +501,7 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
     }
   }
   // snake:219-230 _check_wall_collision
-  o.collision = (e.x - r <= P.margin) || (e.x + r >= P.wall_hi_x) || (e.y - r <= P.margin) || (e.y + r >= P.wall_hi_y);
+  o.collision = (e.x - r <= CV(margin)) || (e.x + r >= CV(wall_hi_x)) || (e.y - r <= CV(margin)) || (e.y + r >= CV(wall_hi_y));
   // snake:278-327 _calculate_snake_reward
   double rew = 0.0;
   if (o.collected) {
@@ -400,20 +509,15 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
     if (P.efficiency_bonus > 0) rew += P.efficiency_bonus * (double)(P.max_steps_wo_food - e.ssf);
   }
   if (o.collision) rew += P.collision_penalty;
+  o.rel = 0.f; o.rel_valid = false;
   if (P.prox_w > 0) {
-    double bd2 = 0.0, bdx = 0.0, bdy = 0.0;
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < FMAX; ++k) {
-      const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
-      const double d2 = dx * dx + dy * dy;
-      if (!is_none(e.fx[k]) && (!any || d2 < bd2)) { any = true; bd2 = d2; bdx = dx; bdy = dy; }
-    }
-    if (any) {
-      // alignment = cos(wrap(atan2(dy,dx) - theta)) = cos(atan2(dy,dx) - theta); fp32 is enough
-      // for a term that only leaves the simulator (snake:301-322)
-      const float ang = atan2f((float)bdy, (float)bdx) - (float)e.th;
-      rew += P.prox_w * (double)cosf(ang);
+    const Nearest g = nearest_food(e);
+    if (g.any) {
+      // alignment = cos(wrap(atan2(dy,dx) - theta)); fp32 is enough for a term that only leaves
+      // the simulator (snake:301-322).  The heading is handed to observe() for reuse.
+      o.rel = relative_heading((float)g.dy, (float)g.dx, (float)e.th);
+      o.rel_valid = true;
+      rew += P.prox_w * (double)cosf(o.rel);
     }
   }
   rew += P.time_penalty;
@@ -422,7 +526,7 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
   if (o.collected) {
     e.fc += 1;
     e.ssf = 0;
-    if (P.respawn) respawn_food(e, P, genv);
+    o.rel_valid = false;  // the food set changed after the reward was computed
   }
   o.terminated = false; o.truncated = false;
   if (o.collision) o.terminated = true;
@@ -440,20 +544,21 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
 }
 
 // legacy:371-388 + snake:366-428: writes the obs row (10 + 4K + 2 floats) to `row` (LDS or global).
-// rmax = max(ellipse_a, ellipse_b) of the current state.
-template <int FMAX, int KMAX>
-__device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, double rmax, float* row) {
+// rmax = max(ellipse_a, ellipse_b) of the current state.  If have_rel, `rel0` is the relative
+// heading of the nearest food already evaluated by the reward for the same food set.
+template <int FMAX, int KMAX, bool STD>
+__device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, double rmax, bool have_rel, float rel0, float* row) {
   const int K = (KMAX == 3) ? 3 : P.K;
-  row[0] = (float)(e.x * P.inv_W);
-  row[1] = (float)(e.y * P.inv_H);
+  row[0] = (float)(e.x * CV(inv_W));
+  row[1] = (float)(e.y * CV(inv_H));
   row[2] = (float)(e.vx * 0.2);
   row[3] = (float)(e.vy * 0.2);
-  row[4] = (float)(e.th * P.inv_pi);
+  row[4] = (float)(e.th * CV(inv_pi));
   row[5] = (float)(e.om * 10.0);
-  row[6] = (float)(rmax * P.inv_R);
+  row[6] = (float)(rmax * CV(inv_R));
   row[7] = (float)bw_phase(e.packed) * 0.5f;
   row[8] = (float)e.water;
-  row[9] = (float)(e.noz * P.inv_max_nozzle);
+  row[9] = (float)(e.noz * CV(inv_max_nozzle));
   // squared distances of live foods in fp64 (the sort key), distances in fp32 (the outputs)
   double d2[FMAX];
   float d[FMAX];
@@ -485,12 +590,16 @@ __device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, 
       if (bi >= 0) {
         left &= ~(1u << bi);
         dsum += bd;
-        float rel = atan2f(by, bx) - th;
-        if (rel > 3.14159265358979f) rel -= 6.28318530717959f;
-        if (rel < -3.14159265358979f) rel += 6.28318530717959f;
-        row[10 + 4 * s + 0] = bx * (float)P.inv_W;
-        row[10 + 4 * s + 1] = by * (float)P.inv_H;
-        row[10 + 4 * s + 2] = bd * P.inv_diag;
+        float rel;
+        if (s == 0) {
+          if (__all(have_rel)) rel = rel0;                    // wave-uniform: skips the second atan2
+          else rel = have_rel ? rel0 : relative_heading(by, bx, th);
+        } else {
+          rel = relative_heading(by, bx, th);
+        }
+        row[10 + 4 * s + 0] = bx * (float)CV(inv_W);
+        row[10 + 4 * s + 1] = by * (float)CV(inv_H);
+        row[10 + 4 * s + 2] = bd * CV(inv_diag);
         row[10 + 4 * s + 3] = rel * 0.318309886183791f;
       } else {
         row[10 + 4 * s + 0] = 0.f; row[10 + 4 * s + 1] = 0.f; row[10 + 4 * s + 2] = 1.f; row[10 + 4 * s + 3] = 0.f;
@@ -501,8 +610,8 @@ __device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, 
 #pragma unroll
   for (int k = 0; k < FMAX; ++k) if ((left >> k) & 1u) dsum += d[k];
   const float fcnt = (float)cnt;
-  row[10 + 4 * K + 0] = fminf(fcnt / 10.0f, 1.0f);
-  row[10 + 4 * K + 1] = (cnt > 0) ? (dsum / fcnt) * P.inv_diag : 1.0f;
+  row[10 + 4 * K + 0] = fminf(fcnt * 0.1f, 1.0f);
+  row[10 + 4 * K + 1] = (cnt > 0) ? (dsum * __frcp_rn(fcnt)) * CV(inv_diag) : 1.0f;
 }
 
 }  // namespace salp

@@ -67,7 +67,9 @@ __device__ __forceinline__ void flush_tile(const float* tile, float* __restrict_
   }
 }
 
-template <int FMAX, int KMAX, bool FORCED>
+// FULL = the common rollout signature (act, obs, reward, terminated, truncated all present; no
+// final_obs / info): no per-step null tests.
+template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL>
 __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H) {
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
   constexpr int PITCH = 4 * QMAX + 4;     // LDS row pitch in floats (pad 16 B: conflict-free b128 writes)
@@ -96,47 +98,29 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
   double st_reward = 0.0, st_epret = 0.0;
   int st_eps = 0, st_term = 0, st_trunc = 0, st_coll = 0, st_food = 0, st_eplen = 0;
 
-  float a0 = 0.f, a1 = 0.f;
-  if (io.act) {
-    a0 = io.act[envc * AD];
-    if (!FORCED) a1 = io.act[envc * AD + 1];
-  }
+  float a0 = io.act[envc * AD];
+  float a1 = FORCED ? 0.f : io.act[envc * AD + 1];
 
 #pragma unroll 1
   for (int t = 0; t < H; ++t) {
     const int64_t rowbase = (int64_t)t * P.n;
-    float c0 = a0, c1 = a1;
-    if (io.act) {
-      if (t + 1 < H) {  // prefetch the next step's action
-        const int64_t nb = (rowbase + P.n + envc) * AD;
-        a0 = io.act[nb];
-        if (!FORCED) a1 = io.act[nb + 1];
-      }
-    } else {
-      const uint32_t ts = (uint32_t)(io.global_step + t);
-      const U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts, 1u, P.seed_lo, P.seed_hi);
-      if (FORCED) {
-        c0 = (float)(w.x >> 8) * 1.1920928955078125e-7f - 1.0f;
-      } else {
-        c0 = (float)(w.x >> 8) * 5.9604644775390625e-8f;
-        const U4 w2 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts, 2u, P.seed_lo, P.seed_hi);
-        c1 = (float)(w2.x >> 8) * 1.1920928955078125e-7f - 1.0f;
-      }
-      if (io.act_out && active) {
-        io.act_out[(rowbase + env) * AD] = c0;
-        if (!FORCED) io.act_out[(rowbase + env) * AD + 1] = c1;
-      }
+    const float c0 = a0, c1 = a1;
+    if (t + 1 < H) {  // prefetch the next step's action
+      const int64_t nb = (rowbase + P.n + envc) * AD;
+      a0 = io.act[nb];
+      if (!FORCED) a1 = io.act[nb + 1];
     }
 
-    const StepOut o = step_env<FMAX, FORCED>(e, P, genv, c0, c1);
+    const StepOut o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
     const bool done = o.terminated || o.truncated;
     double rmax = o.rmax;
+    bool have_rel = o.rel_valid;
 
     if (active) {
-      if (io.reward) io.reward[rowbase + env] = o.reward;
-      if (io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
-      if (io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
-      if (io.info) {
+      if (FULL || io.reward) io.reward[rowbase + env] = o.reward;
+      if (FULL || io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
+      if (FULL || io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
+      if (!FULL && io.info) {
         int32_t* ip = io.info + (rowbase + env) * SALP_INFO_COLS;
         ip[SALP_INFO_FOOD_COLLECTED] = e.fc;
         ip[SALP_INFO_STEPS_SINCE_FOOD] = e.ssf;
@@ -147,18 +131,29 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
     st_food += o.collected ? 1 : 0;
     st_coll += o.collision ? 1 : 0;
 
-    if (__any(done)) {  // rare: same-step autoreset (snake has none; Gymnasium VectorEnv semantics)
-      if (done) {
-        st_eps += 1; st_term += o.terminated ? 1 : 0; st_trunc += o.truncated ? 1 : 0;
-        st_eplen += e.eplen; st_epret += e.epret;
-        if (io.final_obs && active) observe<FMAX, KMAX>(e, P, rmax, io.final_obs + (rowbase + env) * OD);
-        reset_env(e, P, genv);
-        rmax = P.R;
+    // rare events: respawn of a collected food (snake:179-180), then same-step autoreset
+    int todo = (o.collected && P.respawn) ? 1 : 0;
+    if (__any(todo > 0 || done)) {
+      int limit = 50;
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && done) {
+          st_eps += 1; st_term += o.terminated ? 1 : 0; st_trunc += o.truncated ? 1 : 0;
+          st_eplen += e.eplen; st_epret += e.epret;
+          if (!FULL && io.final_obs && active)
+            observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, io.final_obs + (rowbase + env) * OD);
+          todo = reset_pose<FMAX, STD>(e, P, genv);
+          limit = 100;
+          rmax = CV(R);
+          have_rel = false;
+        }
+        place_food<FMAX, STD>(e, P, genv, todo, limit);
+        todo = 0;
       }
     }
 
-    if (io.obs) {
-      observe<FMAX, KMAX>(e, P, rmax, myrow);
+    if (FULL || io.obs) {
+      observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, myrow);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -196,23 +191,51 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
   }
 }
 
+// Device-generated actions (salp_vec_rollout with act == NULL): a[t][env][j] from the env's
+// action stream, Philox counter (env_lo, env_hi, global_step + t, 1 + j).
+__global__ __launch_bounds__(kBlock) void salp_gen_actions_kernel(DevParams P, float* act, int H, int AD, int64_t global_step) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= P.n) return;
+  const uint64_t genv = P.env_base + (uint64_t)i;
+  for (int t = 0; t < H; ++t) {
+    const uint32_t ts = (uint32_t)(global_step + t);
+    const U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts, 1u, P.seed_lo, P.seed_hi);
+    const int64_t o = ((int64_t)t * P.n + i) * AD;
+    if (AD == 1) {
+      act[o] = (float)(w.x >> 8) * 1.1920928955078125e-7f - 1.0f;
+    } else {
+      act[o] = (float)(w.x >> 8) * 5.9604644775390625e-8f;
+      const U4 w2 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts, 2u, P.seed_lo, P.seed_hi);
+      act[o + 1] = (float)(w2.x >> 8) * 1.1920928955078125e-7f - 1.0f;
+    }
+  }
+}
+
 // reset(mask) + observation
-template <int FMAX, int KMAX>
+template <int FMAX, int KMAX, bool STD>
 __global__ __launch_bounds__(kBlock) void salp_reset_kernel(DevParams P, DevState S, const uint8_t* mask, float* obs, int do_reset) {
   const int64_t env = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (env >= P.n) return;
   const uint64_t genv = P.env_base + (uint64_t)env;
   Env<FMAX> e;
   load_env(e, S, P, env);
-  if (do_reset && (!mask || mask[env])) {
-    reset_env(e, P, genv);
+  const bool resetting = do_reset && (!mask || mask[env]);
+  int todo = 0;
+  if (resetting) {
+    const int nf = reset_pose<FMAX, STD>(e, P, genv);
+    // place_food loops until no lane of the wavefront has food left to place; lanes that are not
+    // being reset pass todo = 0
+    todo = nf;
+  }
+  place_food<FMAX, STD>(e, P, genv, todo, 100);
+  if (resetting) {
     store_env(e, S, P, env);
   }
   if (obs) {
     const int K = (KMAX == 3) ? 3 : P.K;
     double a, b;
-    shape_of(P, e.packed, e.water, a, b);
-    observe<FMAX, KMAX>(e, P, pymax(a, b), obs + env * (12 + 4 * K));
+    shape_of<STD>(P, e.packed, e.water, a, b);
+    observe<FMAX, KMAX, STD>(e, P, pymax(a, b), false, 0.f, obs + env * (12 + 4 * K));
   }
 }
 
@@ -230,7 +253,7 @@ __global__ void salp_get_state_kernel(DevParams P, DevState S, double* f64, int3
     const double water = S.f[SF_WATER * p + i];
     f64[SALP_F_WATER * n + i] = water;
     double a, b;
-    shape_of(P, packed, water, a, b);
+    shape_of<false>(P, packed, water, a, b);
     f64[SALP_F_ELLIPSE_A * n + i] = a; f64[SALP_F_ELLIPSE_B * n + i] = b;
     for (int k = 0; k < 2 * P.F; ++k) f64[(SALP_F_FOOD0 + k) * n + i] = S.f[(SF_FOOD0 + k) * p + i];
   }
@@ -293,11 +316,14 @@ struct salp_vec {
   int64_t global_step;
   int obs_dim, act_dim, F, K;
   int fmax, kmax;
+  int std_consts;        // constants equal the reference defaults -> literal-constant kernels
   DevStats* stats;       // device, SALP_STATS_REPLICAS replicas
   int stats_enabled;
   // staging for host-pointer calls (grown on demand)
   void* stage;
   size_t stage_bytes;
+  float* act_buf;        // device-generated actions when the caller gives no act_out
+  size_t act_bytes;
   size_t nf_rows;
 };
 
@@ -359,27 +385,49 @@ int validate(const salp_config_t* c) {
 typedef void (*rollout_fn)(DevParams, DevState, IOPtrs, int);
 typedef void (*reset_fn)(DevParams, DevState, const uint8_t*, float*, int);
 
-template <int FMAX, int KMAX>
-rollout_fn pick_rollout(bool forced) {
-  return forced ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true> : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false>;
+template <int FMAX, int KMAX, bool STD>
+rollout_fn pick_rollout(bool forced, bool full) {
+  if (forced) return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, true>
+                          : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, false>;
+  return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, true>
+              : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, false>;
 }
 
-rollout_fn rollout_kernel_for(const salp_vec* h) {
+// Literal-constant kernels exist for the reference's constants with K = 3 (every preset); any
+// other configuration runs the generic instantiation (runtime constants, F <= 16, K <= 8).
+rollout_fn rollout_kernel_for(const salp_vec* h, bool full) {
   const bool forced = h->P.forced != 0;
-  if (h->kmax == 3) {
-    if (h->fmax == 1) return pick_rollout<1, 3>(forced);
-    if (h->fmax == 4) return pick_rollout<4, 3>(forced);
-    return pick_rollout<16, 3>(forced);
+  if (h->kmax == 3 && h->std_consts) {
+    if (h->fmax == 1) return pick_rollout<1, 3, true>(forced, full);
+    if (h->fmax == 4) return pick_rollout<4, 3, true>(forced, full);
+    return pick_rollout<16, 3, true>(forced, full);
   }
-  return pick_rollout<16, 8>(forced);
+  return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, false>
+                : (rollout_fn)salp_rollout_kernel<16, 8, false, false, false>;
 }
 reset_fn reset_kernel_for(const salp_vec* h) {
-  if (h->kmax == 3) {
-    if (h->fmax == 1) return (reset_fn)salp_reset_kernel<1, 3>;
-    if (h->fmax == 4) return (reset_fn)salp_reset_kernel<4, 3>;
-    return (reset_fn)salp_reset_kernel<16, 3>;
+  if (h->kmax == 3 && h->std_consts) {
+    if (h->fmax == 1) return (reset_fn)salp_reset_kernel<1, 3, true>;
+    if (h->fmax == 4) return (reset_fn)salp_reset_kernel<4, 3, true>;
+    return (reset_fn)salp_reset_kernel<16, 3, true>;
   }
-  return (reset_fn)salp_reset_kernel<16, 8>;
+  return (reset_fn)salp_reset_kernel<16, 8, false>;
+}
+
+// True when every constant of DevParams equals its StdConsts literal (the reference's defaults).
+bool is_std(const DevParams& P) {
+  typedef StdConsts C;
+  return P.W == C::W && P.H == C::H && P.half_W == C::half_W && P.half_H == C::half_H && P.margin == C::margin &&
+         P.wall_hi_x == C::wall_hi_x && P.wall_hi_y == C::wall_hi_y && P.R == C::R && P.a_rest == C::a_rest &&
+         P.b_rest == C::b_rest && P.ab_full == C::ab_full && P.da_inh == C::da_inh && P.db_inh == C::db_inh &&
+         P.da_exh == C::da_exh && P.db_exh == C::db_exh && P.max_nozzle == C::max_nozzle &&
+         P.nozzle_rate == C::nozzle_rate && P.thrust_force == C::thrust_force && P.drag == C::drag &&
+         P.ang_drag == C::ang_drag && P.exhale_dur_d == C::exhale_dur_d && P.food_radius == C::food_radius &&
+         P.min_food_dist2 == C::min_food_dist2 && P.food_xlo == C::food_xlo && P.food_xspan == C::food_xspan &&
+         P.food_ylo == C::food_ylo && P.food_yspan == C::food_yspan && P.inv_W == C::inv_W && P.inv_H == C::inv_H &&
+         P.inv_pi == C::inv_pi && P.inv_R == C::inv_R && P.inv_max_nozzle == C::inv_max_nozzle &&
+         P.inv_diag == C::inv_diag && P.inhale_dur == C::inhale_dur && P.exhale_dur == C::exhale_dur &&
+         P.cycle_len == C::cycle_len;
 }
 
 int ensure_stage(salp_vec* h, size_t bytes) {
@@ -404,7 +452,8 @@ struct Bump {  // carve sub-buffers out of the staging allocation
 
 int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
   const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
-  rollout_fn fn = rollout_kernel_for(h);
+  const bool full = io.obs && io.reward && io.terminated && io.truncated && !io.final_obs && !io.info;
+  rollout_fn fn = rollout_kernel_for(h, full);
   hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H);
   HIP_TRY(hipGetLastError());
   return SALP_OK;
@@ -462,6 +511,7 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
   h->fmax = (h->kmax == 3) ? (h->F <= 1 ? 1 : (h->F <= 4 ? 4 : 16)) : 16;
   const int64_t pitch = (int64_t)align_up((size_t)n_envs, 64);
   h->P = make_params(*cfg, n_envs, pitch, seed, env_index_base);
+  h->std_consts = is_std(h->P) ? 1 : 0;
   h->nf_rows = (size_t)(SF_FOOD0 + 2 * h->F);
   h->stats_enabled = 1;
 
@@ -499,6 +549,7 @@ void salp_vec_destroy(salp_vec_t* h) {
   if (h->S.i) (void)hipFree(h->S.i);
   if (h->stats) (void)hipFree(h->stats);
   if (h->stage) (void)hipFree(h->stage);
+  if (h->act_buf) (void)hipFree(h->act_buf);
   delete h;
 }
 
@@ -568,9 +619,25 @@ static int rollout_impl(salp_vec_t* h, const float* act, int32_t H, float* obs, 
   io.stats = h->stats_enabled ? h->stats : nullptr;
   io.global_step = h->global_step;
   const size_t HN = (size_t)H * (size_t)h->n;
+  const unsigned agrid = (unsigned)((h->n + kBlock - 1) / kBlock);
   if (flags & SALP_DEVICE_PTRS) {
     io.act = act; io.obs = obs; io.reward = reward; io.terminated = terminated; io.truncated = truncated;
     io.final_obs = final_obs; io.info = info; io.act_out = act_out;
+    if (!act) {  // device-generated actions: into act_out when given, else into the handle's buffer
+      float* dst = act_out;
+      if (!dst) {
+        const size_t need_a = HN * h->act_dim * sizeof(float);
+        if (need_a > h->act_bytes) {
+          if (h->act_buf) { (void)hipFree(h->act_buf); h->act_buf = nullptr; h->act_bytes = 0; }
+          HIP_TRY(hipMalloc((void**)&h->act_buf, need_a));
+          h->act_bytes = need_a;
+        }
+        dst = h->act_buf;
+      }
+      hipLaunchKernelGGL(salp_gen_actions_kernel, dim3(agrid), dim3(kBlock), 0, st, h->P, dst, (int)H, h->act_dim, (int64_t)h->global_step);
+      HIP_TRY(hipGetLastError());
+      io.act = dst;
+    }
     int rc = launch_rollout(h, io, H, st);
     if (rc == SALP_OK) h->global_step += H;
     return rc;
@@ -583,8 +650,8 @@ static int rollout_impl(salp_vec_t* h, const float* act, int32_t H, float* obs, 
   int rc = ensure_stage(h, need);
   if (rc != SALP_OK) return rc;
   Bump b{(char*)h->stage, 0};
-  float* d_act = act ? b.take<float>(HN * h->act_dim) : nullptr;
-  float* d_aout = (!act && act_out) ? b.take<float>(HN * h->act_dim) : nullptr;
+  float* d_act = b.take<float>(HN * h->act_dim);
+  float* d_aout = (!act && act_out) ? d_act : nullptr;
   float* d_obs = obs ? b.take<float>(HN * h->obs_dim) : nullptr;
   float* d_fin = final_obs ? b.take<float>(HN * h->obs_dim) : nullptr;
   float* d_rew = reward ? b.take<float>(HN) : nullptr;
@@ -593,6 +660,10 @@ static int rollout_impl(salp_vec_t* h, const float* act, int32_t H, float* obs, 
   int32_t* d_info = info ? b.take<int32_t>(HN * SALP_INFO_COLS) : nullptr;
   if (act) HIP_TRY(hipMemcpyAsync(d_act, act, HN * h->act_dim * sizeof(float), hipMemcpyHostToDevice, st));
   if (final_obs) HIP_TRY(hipMemcpyAsync(d_fin, final_obs, HN * h->obs_dim * sizeof(float), hipMemcpyHostToDevice, st));
+  if (!act) {
+    hipLaunchKernelGGL(salp_gen_actions_kernel, dim3(agrid), dim3(kBlock), 0, st, h->P, d_act, (int)H, h->act_dim, (int64_t)h->global_step);
+    HIP_TRY(hipGetLastError());
+  }
   io.act = d_act; io.obs = d_obs; io.reward = d_rew; io.terminated = d_term; io.truncated = d_trunc;
   io.final_obs = d_fin; io.info = d_info; io.act_out = d_aout;
   rc = launch_rollout(h, io, H, st);
