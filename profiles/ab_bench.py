@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of several builds of libsalp_hip.so in ONE process (same device, same
+data), as cdna_hip_programming.md §5.4 rule 24 asks.  usage:
+    python profiles/ab_bench.py name1=path1.so name2=path2.so ... [--rounds 6] [--launches 5]
+Prints per-variant median / min kernel ms (HIP events) for the bench workload."""
+import ctypes, json, os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import underwater_swimmer_rl_amd as pkg
+from underwater_swimmer_rl_amd import _capi
+
+def main():
+    variants, rounds, launches, n, H, preset = [], 6, 5, 262144, 250, "single_food_long_horizon"
+    it = iter(sys.argv[1:])
+    for a in it:
+        if a == "--rounds": rounds = int(next(it))
+        elif a == "--launches": launches = int(next(it))
+        elif a == "--envs": n = int(next(it))
+        elif a == "--chunk": H = int(next(it))
+        elif a == "--preset": preset = next(it)
+        else:
+            k, v = a.split("=", 1); variants.append((k, os.path.abspath(v)))
+    cfg = pkg.load_env_config(preset)
+    dev = torch.device("cuda", 0)
+    act = torch.rand((H, n, cfg.act_dim), device=dev) * 2 - 1
+    obs = torch.empty((H, n, cfg.obs_dim), device=dev)
+    rew = torch.empty((H, n), device=dev)
+    term = torch.empty((H, n), dtype=torch.uint8, device=dev)
+    trunc = torch.empty((H, n), dtype=torch.uint8, device=dev)
+    handles = {}
+    for name, path in variants:
+        lib = _capi.load_library(path)
+        c = cfg.to_c(); h = ctypes.c_void_p()
+        _capi.check(lib, lib.salp_vec_create(ctypes.byref(c), n, 0, 0, 0, ctypes.byref(h)), "create")
+        handles[name] = (lib, h, c)
+    def launch(name):
+        lib, h, _ = handles[name]
+        vp = ctypes.c_void_p
+        _capi.check(lib, lib.salp_vec_rollout(h, vp(act.data_ptr()), H, vp(obs.data_ptr()), vp(rew.data_ptr()),
+                    vp(term.data_ptr()), vp(trunc.data_ptr()), None, None, 1, vp(torch.cuda.current_stream().cuda_stream)), "rollout")
+    times = {name: [] for name, _ in variants}
+    warm = int(os.environ.get("AB_WARM", "8"))   # advance every variant to the same (desynchronised) phase mix
+    for name, _ in variants:
+        for _ in range(warm): launch(name)
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for name, _ in variants:
+            for _ in range(launches):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); launch(name); e.record(); e.synchronize()
+                times[name].append(s.elapsed_time(e))
+    out = {name: {"median_ms": statistics.median(t), "min_ms": min(t), "max_ms": max(t), "n": len(t)} for name, t in times.items()}
+    print(json.dumps(out, indent=1))
+
+if __name__ == "__main__":
+    main()

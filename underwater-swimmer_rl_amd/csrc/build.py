@@ -23,15 +23,23 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and os.path.isfile(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
-        return OUT
-    cmd = [hipcc()] + FLAGS + ["-o", OUT, SRC]
+def build(force: bool = False, verbose: bool = False, out: str = OUT, defines=()) -> str:
+    """`out`/`defines` build experiment variants (profiles/ab_bench.py); the product is the default."""
+    if not force and os.path.isfile(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+        return out
+    cmd = [hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=HERE)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    out, defs = OUT, []
+    for a in args:
+        if a.startswith("--out="):
+            out = os.path.abspath(a[6:])
+        elif a.startswith("-D"):
+            defs.append(a[2:])
+    print(build(force="--force" in sys.argv, verbose=True, out=out, defines=defs))

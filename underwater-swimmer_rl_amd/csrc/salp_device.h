@@ -383,9 +383,49 @@ __device__ __forceinline__ Nearest nearest_food(const Env<FMAX>& e) {
   return g;
 }
 
-// Heading of the nearest food relative to the body axis, wrapped to [-pi, pi] (fp32).
+// fp32 helpers for quantities that only leave the simulator (observation angle, reward shaping).
+// atan2 for the food bearing: t = min/max via v_rcp_f32 + one Newton step, odd minimax polynomial
+// of degree 17 on [0, 1] (max error ~1e-7 rad), then octant / quadrant unfolding.
+__device__ __forceinline__ float atan2_fast(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  float r = __builtin_amdgcn_rcpf(mx);
+  r = fmaf(fmaf(-mx, r, 1.0f), r, r);           // Newton: r <- r + r(1 - mx r)
+  float t = mn * r;
+  if (!(mx > 0.0f)) t = 0.0f;                    // atan2(0, 0) = 0 (math.atan2 convention)
+  const float z = t * t;
+  float p = fmaf(z, 0.0028662257f, -0.0161657367f);
+  p = fmaf(z, p, 0.0429096138f);
+  p = fmaf(z, p, -0.0752896400f);
+  p = fmaf(z, p, 0.1065626393f);
+  p = fmaf(z, p, -0.1420889944f);
+  p = fmaf(z, p, 0.1999355085f);
+  p = fmaf(z, p, -0.3333314528f);
+  float a = fmaf(t * z, p, t);
+  if (ay > ax) a = 1.57079632679489662f - a;
+  if (x < 0.0f) a = 3.14159265358979324f - a;
+  return (y < 0.0f) ? -a : a;
+}
+
+// cos(x) for |x| <= pi (a wrapped heading): fold to [0, pi/2], even Taylor polynomial to x^14.
+__device__ __forceinline__ float cos_wrapped(float x) {
+  float ax = fabsf(x);
+  const bool flip = ax > 1.57079632679489662f;
+  if (flip) ax = 3.14159265358979324f - ax;
+  const float z = ax * ax;
+  float p = fmaf(z, -1.1470745597729725e-11f, 2.08767569878681e-09f);
+  p = fmaf(z, p, -2.755731922398589e-07f);
+  p = fmaf(z, p, 2.48015873015873e-05f);
+  p = fmaf(z, p, -1.3888888888888889e-03f);
+  p = fmaf(z, p, 4.1666666666666664e-02f);
+  p = fmaf(z, p, -0.5f);
+  const float c = fmaf(z, p, 1.0f);
+  return flip ? -c : c;
+}
+
+// Heading of a food relative to the body axis, wrapped to [-pi, pi] (fp32).
 __device__ __forceinline__ float relative_heading(float dy, float dx, float th) {
-  float rel = atan2f(dy, dx) - th;
+  float rel = atan2_fast(dy, dx) - th;
   if (rel > 3.14159265358979f) rel -= 6.28318530717959f;
   if (rel < -3.14159265358979f) rel += 6.28318530717959f;
   return rel;
@@ -467,6 +507,9 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
     }
   }
   const double r = pymax(a, b);
+#ifdef SALP_EXP_NO_THRUST      // experiment build (profiles/ab_bench.py): price of the thrust block
+  thrust = false;
+#endif
   if (thrust) apply_jet_thrust<FMAX, STD>(e, P, genv, r);
   e.water = water_next;
   e.packed = pack_breath(phase, timer, dur, hold);
@@ -517,7 +560,7 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
       // the simulator (snake:301-322).  The heading is handed to observe() for reuse.
       o.rel = relative_heading((float)g.dy, (float)g.dx, (float)e.th);
       o.rel_valid = true;
-      rew += P.prox_w * (double)cosf(o.rel);
+      rew += P.prox_w * (double)cos_wrapped(o.rel);
     }
   }
   rew += P.time_penalty;
@@ -543,22 +586,24 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
   return o;
 }
 
-// legacy:371-388 + snake:366-428: writes the obs row (10 + 4K + 2 floats) to `row` (LDS or global).
+// legacy:371-388 + snake:366-428: the observation row (10 + 4K + 2 floats) in registers `o`.
 // rmax = max(ellipse_a, ellipse_b) of the current state.  If have_rel, `rel0` is the relative
 // heading of the nearest food already evaluated by the reward for the same food set.
 template <int FMAX, int KMAX, bool STD>
-__device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, double rmax, bool have_rel, float rel0, float* row) {
+__device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, double rmax, bool have_rel, float rel0,
+                                        float (&o)[12 + 4 * KMAX]) {
   const int K = (KMAX == 3) ? 3 : P.K;
-  row[0] = (float)(e.x * CV(inv_W));
-  row[1] = (float)(e.y * CV(inv_H));
-  row[2] = (float)(e.vx * 0.2);
-  row[3] = (float)(e.vy * 0.2);
-  row[4] = (float)(e.th * CV(inv_pi));
-  row[5] = (float)(e.om * 10.0);
-  row[6] = (float)(rmax * CV(inv_R));
-  row[7] = (float)bw_phase(e.packed) * 0.5f;
-  row[8] = (float)e.water;
-  row[9] = (float)(e.noz * CV(inv_max_nozzle));
+  // normalisations in fp32 on the rounded fp64 state (<= 1.5 ulp of the reference's f32 value)
+  o[0] = (float)e.x * (float)CV(inv_W);
+  o[1] = (float)e.y * (float)CV(inv_H);
+  o[2] = (float)e.vx * 0.2f;
+  o[3] = (float)e.vy * 0.2f;
+  o[4] = (float)e.th * (float)CV(inv_pi);
+  o[5] = (float)e.om * 10.0f;
+  o[6] = (float)rmax * (float)CV(inv_R);
+  o[7] = (float)bw_phase(e.packed) * 0.5f;
+  o[8] = (float)e.water;
+  o[9] = (float)e.noz * (float)CV(inv_max_nozzle);
   // squared distances of live foods in fp64 (the sort key), distances in fp32 (the outputs)
   double d2[FMAX];
   float d[FMAX];
@@ -569,7 +614,7 @@ __device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, 
     const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
     d2[k] = dx * dx + dy * dy;
     const bool ok = !is_none(e.fx[k]);
-    d[k] = __fsqrt_rn((float)d2[k]);
+    d[k] = __builtin_amdgcn_sqrtf((float)d2[k]);
     if (ok) { live |= (1u << k); ++cnt; }
   }
   const float th = (float)e.th;
@@ -578,6 +623,7 @@ __device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, 
   uint32_t left = live;
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) {
+    float v0 = 0.f, v1 = 0.f, v2 = 1.f, v3 = 0.f;   // padding for an empty slot (snake:412)
     if (s < K) {
       double bd2 = 0.0;
       float bd = 0.f, bx = 0.f, by = 0.f;
@@ -597,21 +643,27 @@ __device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, 
         } else {
           rel = relative_heading(by, bx, th);
         }
-        row[10 + 4 * s + 0] = bx * (float)CV(inv_W);
-        row[10 + 4 * s + 1] = by * (float)CV(inv_H);
-        row[10 + 4 * s + 2] = bd * CV(inv_diag);
-        row[10 + 4 * s + 3] = rel * 0.318309886183791f;
-      } else {
-        row[10 + 4 * s + 0] = 0.f; row[10 + 4 * s + 1] = 0.f; row[10 + 4 * s + 2] = 1.f; row[10 + 4 * s + 3] = 0.f;
+        v0 = bx * (float)CV(inv_W);
+        v1 = by * (float)CV(inv_H);
+        v2 = bd * CV(inv_diag);
+        v3 = rel * 0.318309886183791f;
       }
     }
+    o[10 + 4 * s + 0] = v0; o[10 + 4 * s + 1] = v1; o[10 + 4 * s + 2] = v2; o[10 + 4 * s + 3] = v3;
   }
   // the mean distance runs over ALL live foods (snake:418-420), not only the K observed
 #pragma unroll
   for (int k = 0; k < FMAX; ++k) if ((left >> k) & 1u) dsum += d[k];
   const float fcnt = (float)cnt;
-  row[10 + 4 * K + 0] = fminf(fcnt * 0.1f, 1.0f);
-  row[10 + 4 * K + 1] = (cnt > 0) ? (dsum * __frcp_rn(fcnt)) * CV(inv_diag) : 1.0f;
+  const float s0 = fminf(fcnt * 0.1f, 1.0f);
+  const float s1 = (cnt > 0) ? (dsum * __builtin_amdgcn_rcpf(fcnt)) * CV(inv_diag) : 1.0f;
+  // the two summary values sit right after the K-th food block
+  if (KMAX == 3) {
+    o[22] = s0; o[23] = s1;
+  } else {
+#pragma unroll
+    for (int s = 0; s <= KMAX; ++s) if (s == K) { o[10 + 4 * s] = s0; o[11 + 4 * s] = s1; }
+  }
 }
 
 }  // namespace salp

@@ -27,6 +27,7 @@ using namespace salp;
 
 namespace {
 
+typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 
@@ -54,19 +55,6 @@ struct IOPtrs {
   int64_t global_step;    // step index of t = 0 (device-generated actions)
 };
 
-// Streams one wavefront's staged tile (rows x Q float4, LDS pitch PITCH floats) to global memory
-// as contiguous 16-B-per-lane stores.  `rows` = live rows of this wavefront (<= 64).
-template <int PITCH>
-__device__ __forceinline__ void flush_tile(const float* tile, float* __restrict__ gbase, int Q, int rows, int lane) {
-  const int total = rows * Q;  // float4 count
-  for (int f = lane; f < total; f += kWave) {
-    const int r = f / Q;
-    const int c = f - r * Q;
-    const float4 v = *reinterpret_cast<const float4*>(tile + r * PITCH + 4 * c);
-    *reinterpret_cast<float4*>(gbase + (int64_t)f * 4) = v;
-  }
-}
-
 // FULL = the common rollout signature (act, obs, reward, terminated, truncated all present; no
 // final_obs / info): no per-step null tests.
 template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL>
@@ -78,7 +66,13 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid / kWave;
-  const int64_t env0 = (int64_t)blockIdx.x * kBlock + (int64_t)wave * kWave;  // first env of this wavefront
+#ifdef SALP_EXP_XCD_REMAP   // blocks are dealt round-robin over the 8 XCDs: give each XCD a contiguous env range
+  const unsigned nb = gridDim.x;
+  const unsigned bid = (nb % 8 == 0) ? ((blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8) : blockIdx.x;
+#else
+  const unsigned bid = blockIdx.x;
+#endif
+  const int64_t env0 = (int64_t)bid * kBlock + (int64_t)wave * kWave;  // first env of this wavefront
   const int64_t env = env0 + lane;
   const bool active = env < P.n;
   const int64_t envc = active ? env : (P.n - 1);
@@ -89,7 +83,17 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
   const int OD = 4 * Q;
   const int AD = FORCED ? 1 : 2;
   float* tile = lds + wave * kWave * PITCH;
-  float* myrow = tile + lane * PITCH;
+  float4* myrow4 = reinterpret_cast<float4*>(tile + lane * PITCH);
+
+  // Tile flush plan, fixed for the whole launch: float4 number f = j*64 + lane of the wavefront's
+  // [rows x Q] tile lives at LDS row f / Q, column f % Q and goes to global float4 f of the run.
+  int lds_off[QMAX];      // float offset inside the tile, or -1 when this lane has nothing to move
+#pragma unroll
+  for (int j = 0; j < QMAX; ++j) {
+    const int f = j * kWave + lane;
+    const int r = f / Q;
+    lds_off[j] = (j < Q && f < rows * Q) ? (r * PITCH + 4 * (f - r * Q)) : -1;
+  }
 
   Env<FMAX> e;
   load_env(e, S, P, envc);
@@ -98,6 +102,9 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
   double st_reward = 0.0, st_epret = 0.0;
   int st_eps = 0, st_term = 0, st_trunc = 0, st_coll = 0, st_food = 0, st_eplen = 0;
 
+#ifdef SALP_EXP_STAGGER   // experiment: offset the four wavefronts of a SIMD by a quarter step each
+  for (int k = 0; k < (int)((blockIdx.x >> SALP_EXP_STAGGER_SHIFT) & 3) * SALP_EXP_STAGGER; ++k) __builtin_amdgcn_s_sleep(24);
+#endif
   float a0 = io.act[envc * AD];
   float a1 = FORCED ? 0.f : io.act[envc * AD + 1];
 
@@ -111,16 +118,29 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
       if (!FORCED) a1 = io.act[nb + 1];
     }
 
+#ifdef SALP_EXP_STORE_ONLY   // experiment build: no simulation, only the output stream
+    StepOut o; o.rmax = 30.0; o.reward = c0; o.rel = c1; o.rel_valid = true;
+    o.terminated = o.truncated = o.collision = o.collected = false;
+#else
     const StepOut o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
+#endif
     const bool done = o.terminated || o.truncated;
     double rmax = o.rmax;
     bool have_rel = o.rel_valid;
 
-    if (active) {
-      if (FULL || io.reward) io.reward[rowbase + env] = o.reward;
-      if (FULL || io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
-      if (FULL || io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
-      if (!FULL && io.info) {
+#ifdef SALP_EXP_NO_SMALL_STORES
+    if (rows < 0)
+#endif
+    {
+      // reward: one dword per lane (256 B per wavefront); flags: one byte per lane.  (Rebuilding the
+      // 64 flag bytes from a ballot and storing 16 dwords was measured: no faster in the memory
+      // pipeline and slower overall, profiles/r01/ab_notes.md.)
+      if (active && (FULL || io.reward)) io.reward[rowbase + env] = o.reward;
+      if (active) {
+        if (FULL || io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
+        if (FULL || io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
+      }
+      if (active && !FULL && io.info) {
         int32_t* ip = io.info + (rowbase + env) * SALP_INFO_COLS;
         ip[SALP_INFO_FOOD_COLLECTED] = e.fc;
         ip[SALP_INFO_STEPS_SINCE_FOOD] = e.ssf;
@@ -140,8 +160,14 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
         if (pass == 1 && done) {
           st_eps += 1; st_term += o.terminated ? 1 : 0; st_trunc += o.truncated ? 1 : 0;
           st_eplen += e.eplen; st_epret += e.epret;
-          if (!FULL && io.final_obs && active)
-            observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, io.final_obs + (rowbase + env) * OD);
+          if (!FULL && io.final_obs && active) {
+            float fo[12 + 4 * KMAX];
+            observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, fo);
+            float4* dst = reinterpret_cast<float4*>(io.final_obs + (rowbase + env) * OD);
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q)
+              if (q < Q) dst[q] = make_float4(fo[4 * q], fo[4 * q + 1], fo[4 * q + 2], fo[4 * q + 3]);
+          }
           todo = reset_pose<FMAX, STD>(e, P, genv);
           limit = 100;
           rmax = CV(R);
@@ -153,11 +179,26 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
     }
 
     if (FULL || io.obs) {
-      observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, myrow);
+      float ob[12 + 4 * KMAX];
+      observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
+#pragma unroll
+      for (int q = 0; q < QMAX; ++q)   // 16-B LDS stores at a 16-B-padded pitch: conflict-free
+        if (q < Q) myrow4[q] = make_float4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      flush_tile<PITCH>(tile, io.obs + (rowbase + env0) * OD, Q, rows, lane);
+      float4* gout = reinterpret_cast<float4*>(io.obs + (rowbase + env0) * OD) + lane;
+#ifdef SALP_EXP_NO_OBS_STORE    // experiment build: everything but the observation stream
+      if (rows < 0)
+#endif
+#pragma unroll
+      for (int j = 0; j < QMAX; ++j) {
+#ifdef SALP_EXP_PLAIN_STORE
+        if (lds_off[j] >= 0) gout[j * kWave] = *reinterpret_cast<const float4*>(tile + lds_off[j]);
+#else   // write-once stream far larger than L2 / Infinity Cache: non-temporal (measured -2.4 %)
+        if (lds_off[j] >= 0) __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(tile + lds_off[j]), reinterpret_cast<v4f*>(&gout[j * kWave]));
+#endif
+      }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -235,7 +276,12 @@ __global__ __launch_bounds__(kBlock) void salp_reset_kernel(DevParams P, DevStat
     const int K = (KMAX == 3) ? 3 : P.K;
     double a, b;
     shape_of<STD>(P, e.packed, e.water, a, b);
-    observe<FMAX, KMAX, STD>(e, P, pymax(a, b), false, 0.f, obs + env * (12 + 4 * K));
+    float ob[12 + 4 * KMAX];
+    observe<FMAX, KMAX, STD>(e, P, pymax(a, b), false, 0.f, ob);
+    float4* dst = reinterpret_cast<float4*>(obs + env * (12 + 4 * K));
+#pragma unroll
+    for (int q = 0; q < 3 + KMAX; ++q)
+      if (q < 3 + K) dst[q] = make_float4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
   }
 }
 
