@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors by running the REFERENCE's own SalpSnakeEnv
+(tests/golden/ref_harness.py) in the build container.  Run:  python tests/golden/gen_golden.py
+
+Each fixture `ref_<case>.npz` holds inputs and expected outputs only (no reference source):
+  cfg_json      the 13 reference kwargs + seed / env_index_base / case notes
+  actions       f32 [H, N, act_dim]
+  inject_f64 / inject_i32 (optional)  state snapshot rows written before the first step
+                (public layout of include/salp_vec.h; what eval/collect_navigation_data.py:76-89 pokes)
+  reset_obs     f32 [N, obs_dim]      observation after the (injected) reset
+  obs           f32 [H, N, obs_dim]   returned observation (post-autoreset on finished steps)
+  final_obs     f32 [H, N, obs_dim]   terminal observation on finished steps, NaN elsewhere
+  reward        f64 [H, N]
+  terminated, truncated  u8 [H, N]
+  info          i32 [H, N, 3]         food_collected, steps_since_food, collision (pre-autoreset)
+  end_f64 / end_i32   state snapshot after the last step
+Autoreset is emulated the way a VectorEnv would drive the reference: when step() reports
+terminated or truncated, reset() is called and its observation replaces the returned one.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_harness as rh  # noqa: E402
+import underwater_swimmer_rl_amd as pkg  # noqa: E402
+
+F_X, F_Y, F_VX, F_VY, F_THETA, F_OMEGA, F_NOZZLE, F_WATER, F_ELLIPSE_A, F_ELLIPSE_B, F_FOOD0 = range(11)
+(I_PHASE, I_TIMER, I_EXHALE_DUR, I_SHAPE_HOLD, I_STEPS_SINCE_FOOD, I_FOOD_COLLECTED, I_RNG_COUNTER,
+ I_EPISODE_LENGTH, I_COUNT) = range(9)
+
+
+def snapshot(envs, F):
+    n = len(envs)
+    f64 = np.full((F_FOOD0 + 2 * F, n), np.nan)
+    i32 = np.zeros((I_COUNT, n), np.int32)
+    for i, r in enumerate(envs):
+        s = r.state()
+        f64[F_X, i], f64[F_Y, i], f64[F_VX, i], f64[F_VY, i] = s["x"], s["y"], s["vx"], s["vy"]
+        f64[F_THETA, i], f64[F_OMEGA, i], f64[F_NOZZLE, i], f64[F_WATER, i] = s["theta"], s["omega"], s["nozzle"], s["water"]
+        f64[F_ELLIPSE_A, i], f64[F_ELLIPSE_B, i] = s["ellipse_a"], s["ellipse_b"]
+        for k in range(min(F, len(s["food"]))):
+            f64[F_FOOD0 + k, i] = s["food"][k, 0]
+            f64[F_FOOD0 + F + k, i] = s["food"][k, 1]
+        i32[I_PHASE, i], i32[I_TIMER, i], i32[I_EXHALE_DUR, i] = s["phase"], s["timer"], s["exhale_dur"]
+        i32[I_STEPS_SINCE_FOOD, i], i32[I_FOOD_COLLECTED, i] = s["steps_since_food"], s["food_collected"]
+        i32[I_RNG_COUNTER, i] = s["rng_counter"]
+        i32[I_EPISODE_LENGTH, i] = r.episode_length
+        i32[I_SHAPE_HOLD, i] = r.shape_hold
+    return f64, i32
+
+
+def apply_injection(r, col, f64, F):
+    """Writes pose / food the way the reference's eval scripts poke attributes."""
+    e = r.env
+    e.robot_pos = np.array([f64[F_X, col], f64[F_Y, col]], dtype=float)
+    e.robot_velocity = np.array([f64[F_VX, col], f64[F_VY, col]], dtype=float)
+    e.robot_angle = float(f64[F_THETA, col])
+    e.robot_angular_velocity = float(f64[F_OMEGA, col])
+    foods = []
+    for k in range(F):
+        x, y = f64[F_FOOD0 + k, col], f64[F_FOOD0 + F + k, col]
+        foods.append(None if (math.isnan(x) or math.isnan(y)) else [float(x), float(y)])
+    e.food_positions = foods
+    e.steps_since_food = 0
+
+
+ESCAPES = [0]
+
+
+def run_case(name, params, actions, seed, base=0, inject=None, notes=""):
+    ESCAPES[0] = 0
+    cfg = pkg.load_env_config(params.pop("preset"), **params) if "preset" in params else pkg.SalpSnakeConfig(**params)
+    H, n, ad = actions.shape
+    assert ad == cfg.act_dim
+    F, od = cfg.num_food_items, cfg.obs_dim
+    envs = [rh.ReferenceEnv(seed, base + i, **cfg.env_kwargs()) for i in range(n)]
+    for r in envs:
+        r.episode_length = 0
+        r.shape_hold = 7
+    reset_obs = np.stack([r.reset() for r in envs]).astype(np.float32)
+    inj_f64 = inj_i32 = None
+    if inject is not None:
+        inj_f64, inj_i32 = snapshot(envs, F)
+        inject(inj_f64, inj_i32)
+        for i, r in enumerate(envs):
+            apply_injection(r, i, inj_f64, F)
+        inj_i32[I_STEPS_SINCE_FOOD] = 0
+        reset_obs = np.stack([r.env._get_extended_observation() for r in envs]).astype(np.float32)
+    obs = np.zeros((H, n, od), np.float32)
+    fin = np.full((H, n, od), np.nan, np.float32)
+    rew = np.zeros((H, n), np.float64)
+    term = np.zeros((H, n), np.uint8)
+    trunc = np.zeros((H, n), np.uint8)
+    info = np.zeros((H, n, 3), np.int32)
+    for t in range(H):
+        for i, r in enumerate(envs):
+            pre_phase, pre_timer = r.env.breathing_phase, r.env.breathing_timer
+            o, rw, te, tr, inf = r.step(actions[t, i])
+            r.episode_length += 1
+            # bookkeeping the build adds (SALP_I_SHAPE_HOLD): an early release that returned to rest
+            r.shape_hold = pre_timer if (pre_phase == "inhaling" and r.env.breathing_phase == "rest"
+                                         and 1 <= pre_timer <= 6) else 0
+            rr = max(r.env.ellipse_a, r.env.ellipse_b)
+            m = r.env.tank_margin + rr
+            clamped = (r.env.robot_pos[0] in (m, r.env.width - m)) or (r.env.robot_pos[1] in (m, r.env.height - m))
+            if clamped and not inf["collision"]:
+                ESCAPES[0] += 1
+            rew[t, i], term[t, i], trunc[t, i] = rw, te, tr
+            info[t, i] = (inf["food_collected"], inf["steps_since_food"], int(inf["collision"]))
+            if te or tr:
+                fin[t, i] = o
+                o = r.reset()
+                r.episode_length = 0
+                r.shape_hold = 7
+            obs[t, i] = o
+    end_f64, end_i32 = snapshot(envs, F)
+    meta = dict(cfg.env_kwargs(), seed=seed, env_index_base=base, case=name, notes=notes)
+    out = dict(cfg_json=np.array(json.dumps(meta)), actions=actions, reset_obs=reset_obs, obs=obs, final_obs=fin,
+               reward=rew, terminated=term, truncated=trunc, info=info, end_f64=end_f64, end_i32=end_i32)
+    if inj_f64 is not None:
+        out["inject_f64"], out["inject_i32"] = inj_f64, inj_i32
+    path = os.path.join(HERE, f"ref_{name}.npz")
+    np.savez_compressed(path, **out)
+    ev = dict(terminated=int(term.sum()), truncated=int(trunc.sum()), food=int(info[..., 0].max()),
+              collisions=int(info[..., 2].sum()), wall_clamps_without_collision=ESCAPES[0])
+    print(f"{name:28s} H={H:5d} N={n:2d} {ev}  -> {os.path.getsize(path) / 1024:.0f} KiB")
+    return ev
+
+
+def uniform_actions(H, n, ad, seed, lo=-1.0, hi=1.0):
+    return np.random.default_rng(seed).uniform(lo, hi, size=(H, n, ad)).astype(np.float32)
+
+
+def main():
+    # --- the three BASELINE presets, 8 envs x 256 steps
+    for k, preset in enumerate(("single_food", "single_food_long_horizon", "sac_gail")):
+        cfg = pkg.load_env_config(preset)
+        run_case(preset, dict(preset=preset), uniform_actions(256, 8, cfg.act_dim, 100 + k), seed=1000 + k,
+                 notes="BASELINE preset, random actions")
+
+    # --- wall hits: terminations, corner hits and the rounding-escape case
+    a = uniform_actions(3000, 6, 1, 7)
+    a[:, 0] = 0.0          # straight runs hit the right wall
+    a[:, 1] = 0.35
+    a[:, 2] = -0.6
+    ev = run_case("wall_events", dict(preset="single_food"), a, seed=77, notes="straight and curved runs into walls")
+    assert ev["terminated"] >= 4
+
+    # --- many wall contacts in a row: swimmers injected next to the right / bottom walls moving
+    #     outward.  Includes contacts that do NOT terminate: after legacy:335-352 clamps pos = m + r,
+    #     snake:225-228 tests pos - r <= margin in fp64, and (50 + r) - r is sometimes 50 + 1 ulp.
+    def rush(f64, i32):
+        n = f64.shape[1]
+        f64[F_X] = 650.0 + 3.0 * np.arange(n)
+        f64[F_Y] = 300.0 + 12.0 * np.arange(n)
+        f64[F_VX] = 1.5
+        f64[F_VY] = 0.25 * np.arange(n)
+        f64[F_THETA] = 0.1 * np.arange(n) - 0.8
+    ev = run_case("wall_rush", dict(preset="single_food_long_horizon"), uniform_actions(500, 16, 1, 31), seed=32,
+                  inject=rush, notes="contacts with the right and bottom walls, some escape termination")
+    assert ev["terminated"] >= 16
+
+    # --- food capture + respawn (food placed ahead of the swimmer), efficiency bonus on
+    def ahead(f64, i32):
+        f64[F_FOOD0] = [455.0, 470.0, 520.0, 600.0]
+        f64[F_FOOD0 + 1] = [300.0, 300.0, 310.0, 295.0]
+    ev = run_case("food_capture_respawn", dict(preset="single_food", efficiency_bonus=0.5),
+                  np.zeros((1500, 4, 1), np.float32), seed=5, inject=ahead, notes="food ahead of a straight swimmer")
+    assert ev["food"] >= 1
+
+    # --- respawn_food=False: episode ends when the last food is collected
+    def two_ahead(f64, i32):
+        f64[F_FOOD0] = [452.0, 452.0]
+        f64[F_FOOD0 + 1] = [540.0, 560.0]
+        f64[F_FOOD0 + 2] = [300.0, 300.0]
+        f64[F_FOOD0 + 3] = [300.0, 305.0]
+    ev = run_case("no_respawn_completion", dict(preset="sac_gail", num_food_items=2, respawn_food=False),
+                  np.zeros((1500, 2, 1), np.float32), seed=6, inject=two_ahead, notes="all food collected -> terminated")
+    assert ev["terminated"] >= 1
+
+    # --- truncation at steps_since_food > max
+    ev = run_case("truncation", dict(preset="single_food", max_steps_without_food=40), uniform_actions(130, 3, 1, 9),
+                  seed=8, notes="truncated at step 41, 82, 123")
+    assert ev["truncated"] == 9
+
+    # --- free breathing: early release (water <= 0.05 -> rest), short inhale (dur = 45), full inhale
+    H, n = 900, 4
+    a = np.zeros((H, n, 2), np.float32)
+    a[..., 1] = uniform_actions(H, n, 1, 11)[..., 0]
+    pat = [(3, 10), (20, 60), (121, 170), (6, 9), (7, 50), (60, 90), (36, 80), (200, 60)]   # (hold, release) steps
+    for i in range(n):
+        t = 0
+        j = i
+        while t < H:
+            hold, rel = pat[j % len(pat)]
+            a[t:t + hold, i, 0] = 0.9
+            a[t + hold:t + hold + rel, i, 0] = 0.2
+            t += hold + rel
+            j += 1
+    run_case("free_breathing", dict(preset="single_food", forced_breathing=False), a, seed=12,
+             notes="2-action mode: early release, scaled exhale duration")
+
+    # --- random food count, 5 foods, short episodes so resets re-draw the count
+    run_case("random_food_count", dict(preset="sac_gail", num_food_items=5, random_food_count=True,
+                                       max_steps_without_food=60), uniform_actions(400, 6, 1, 13), seed=14,
+             notes="randint(1,5) per episode")
+
+    # --- K=2 of F=6 with the alignment reward, and K=0
+    run_case("k2_of_6", dict(preset="sac_gail", num_food_items=6, max_observed_food=2, proximity_reward_weight=2.0),
+             uniform_actions(300, 4, 1, 15), seed=16, notes="sorting: 2 nearest of 6")
+    run_case("k0", dict(preset="single_food", max_observed_food=0), uniform_actions(200, 2, 1, 17), seed=18,
+             notes="obs_dim 12")
+
+    # --- 12 foods crowded: rejection sampling with many rejected attempts
+    run_case("crowded_f16", dict(preset="sac_gail", num_food_items=16, max_steps_without_food=50),
+             uniform_actions(160, 3, 1, 19), seed=20, notes="16 foods, frequent resets")
+
+    # --- out-of-range and NaN actions (not clipped by the reference)
+    a = uniform_actions(300, 4, 1, 21, -3.0, 3.0)
+    a[40:60, 1, 0] = np.nan
+    a[100, 2, 0] = np.inf
+    run_case("wild_actions", dict(preset="single_food"), a, seed=22, notes="|a| up to 3, NaN, inf")
+
+    # --- env_index_base: the same global envs from a shard
+    run_case("shard_base_1000", dict(preset="single_food_long_horizon"), uniform_actions(128, 4, 1, 23), seed=1001,
+             base=1000, notes="global env indices 1000..1003")
+
+
+if __name__ == "__main__":
+    if not rh.reference_available():
+        raise SystemExit("reference not found under /root/reference: golden vectors can only be generated in the build container")
+    main()

@@ -257,7 +257,7 @@ class ReferenceEnv:
             nozzle=float(e.nozzle_angle), water=float(e.water_volume),
             ellipse_a=float(e.ellipse_a), ellipse_b=float(e.ellipse_b),
             phase=phase, timer=int(e.breathing_timer),
-            exhale_dur=int(getattr(e, "current_exhale_duration", e.exhale_duration)),
+            exhale_dur=int(getattr(e, "current_exhale_duration", 0)),  # 0 = not yet set (legacy:233 getattr default is only read while exhaling)
             food=np.array(foods, dtype=np.float64).reshape(-1, 2),
             steps_since_food=int(e.steps_since_food), food_collected=int(e.food_collected),
             score=float(e.score), rng_counter=int(self.stream.counter),

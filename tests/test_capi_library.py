@@ -1,0 +1,81 @@
+"""The C-ABI library loads and exports every symbol include/salp_vec.h declares (no compute
+calls: this runs without a GPU), and it fails loudly instead of falling back to a CPU path."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import underwater_swimmer_rl_amd as pkg
+from underwater_swimmer_rl_amd import _capi
+from underwater_swimmer_rl_amd.config import CConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "salp_vec.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(salp_[a-z_0-9]+)\s*\(", src)
+    return sorted(set(n for n in names if not n.endswith("_t")))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_salp_build", os.path.join(ROOT, "underwater-swimmer_rl_amd", "csrc", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build()
+    return _capi.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/salp_vec.h but not exported"
+    assert set(_capi.EXPORTS) == set(names)
+
+
+def test_abi_version_and_config_layout(lib):
+    assert lib.salp_abi_version() == 1
+    c = CConfig()
+    assert lib.salp_config_default(ctypes.byref(c)) == 0
+    assert c.struct_size == ctypes.sizeof(CConfig)
+    d = pkg.SalpSnakeConfig()          # python defaults == C defaults == snake:29-33 / legacy:32-53
+    e = d.to_c()
+    for name, _ in CConfig._fields_:
+        assert getattr(c, name) == getattr(e, name), name
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device create() must fail with SALP_ERR_NO_DEVICE, never simulate on the CPU."""
+    if lib.salp_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    c = pkg.load_env_config("single_food").to_c()
+    h = ctypes.c_void_p()
+    rc = lib.salp_vec_create(ctypes.byref(c), 64, 0, 0, 0, ctypes.byref(h))
+    assert rc == -2 and not h
+    assert b"no HIP device" in lib.salp_last_error()
+    with pytest.raises(_capi.SalpError):
+        pkg.SalpVectorEnv("single_food", 64, output="numpy")
+
+
+def test_bad_config_is_rejected_before_touching_the_device(lib):
+    c = pkg.load_env_config("single_food").to_c()
+    h = ctypes.c_void_p()
+    c.struct_size = 4
+    assert lib.salp_vec_create(ctypes.byref(c), 64, 0, 0, 0, ctypes.byref(h)) == -1
+    c = pkg.load_env_config("single_food").to_c()
+    c.num_food_items = 99
+    assert lib.salp_vec_create(ctypes.byref(c), 64, 0, 0, 0, ctypes.byref(h)) == -1
+    assert lib.salp_vec_create(None, 64, 0, 0, 0, ctypes.byref(h)) == -1
+    assert lib.salp_vec_num_envs(None) == 0 and lib.salp_vec_obs_dim(None) == 0
+    lib.salp_vec_destroy(None)  # no-op
+
+
+def test_missing_library_raises(tmp_path):
+    with pytest.raises(_capi.SalpError):
+        _capi.load_library(str(tmp_path / "nope.so"))

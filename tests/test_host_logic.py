@@ -1,0 +1,78 @@
+"""Host-side mirror of the reference interface: parameters, spaces, SB3 adapter plumbing, bench maths."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import underwater_swimmer_rl_amd as pkg
+from underwater_swimmer_rl_amd import spaces
+from underwater_swimmer_rl_amd.vector_env import _LazyInfos
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_defaults_are_the_reference_kwargs():
+    c = pkg.SalpSnakeConfig()
+    # snake:29-33
+    assert (c.width, c.height, c.num_food_items, c.food_reward, c.collision_penalty) == (800, 600, 5, 10.0, -50.0)
+    assert (c.time_penalty, c.efficiency_bonus, c.forced_breathing, c.max_observed_food) == (-0.1, 1.0, True, 3)
+    assert (c.random_food_count, c.respawn_food, c.proximity_reward_weight, c.max_steps_without_food) == (False, True, 0.0, 1500)
+    # legacy:32-53
+    assert (c.tank_margin, c.base_radius, c.max_thrust_force, c.drag_coefficient) == (50.0, 30.0, 100.0, 0.98)
+    assert c.max_nozzle_angle == math.pi / 3 and c.nozzle_response_rate == 0.05
+    assert (c.inhale_duration, c.exhale_duration, c.rest_duration) == (120, 150, 60)
+    assert c.obs_dim == 24 and c.act_dim == 1
+
+
+def test_presets_and_overrides():
+    c = pkg.load_env_config("single_food_long_horizon")
+    assert c.collision_penalty == -500.0 and c.max_steps_without_food == 2000 and c.num_food_items == 1
+    assert pkg.load_env_config("sac_gail").num_food_items == 12
+    assert pkg.load_env_config("single_food", forced_breathing=False).act_dim == 2
+    assert pkg.SalpSnakeConfig(num_food_items=-3).num_food_items == 0       # snake:36 max(0, n)
+    with pytest.raises(TypeError):
+        pkg.load_env_config("single_food", not_a_param=1)
+    with pytest.raises(ValueError):
+        pkg.SalpSnakeConfig(num_food_items=17)
+    with pytest.raises(FileNotFoundError):
+        pkg.load_env_config("no_such_preset")
+
+
+def test_yaml_loader(tmp_path):
+    p = tmp_path / "x.yaml"
+    p.write_text("environment:\n  width: 999\n  params:\n    num_food_items: 2\n    food_reward: 3.5\n")
+    c = pkg.load_env_config(str(p))
+    assert c.num_food_items == 2 and c.food_reward == 3.5 and c.width == 800  # train.py:50-52 drops width/height
+
+
+def test_spaces_match_snake_69_88():
+    cfg = pkg.load_env_config("single_food")
+    a, o = spaces.single_action_space(cfg), spaces.single_observation_space(cfg)
+    assert a.shape == (1,) and a.low[0] == -1 and a.high[0] == 1 and a.dtype == np.float32
+    assert o.shape == (24,) and o.low[4] == np.float32(-math.pi) and o.high[6] == 2.0 and o.low[10] == -1
+    a2 = spaces.single_action_space(pkg.load_env_config("single_food", forced_breathing=False))
+    assert a2.shape == (2,) and list(a2.low) == [0.0, -1.0] and list(a2.high) == [1.0, 1.0]
+    b = spaces.batch_space(o, 7)
+    assert b.shape == (7, 24) and a.contains(a.sample())
+
+
+def test_lazy_infos_behave_like_a_list_of_dicts():
+    n = 5
+    dones = np.array([0, 1, 0, 1, 0], bool)
+    truncs = np.array([0, 1, 0, 0, 0], bool)
+    tobs = np.arange(n * 3, dtype=np.float32).reshape(n, 3)
+    inf = _LazyInfos(n, np.arange(n), np.arange(n) * 2, np.zeros(n, np.int32), dones, truncs, tobs, 10.0)
+    assert len(inf) == n and inf[1]["TimeLimit.truncated"] and not inf[3]["TimeLimit.truncated"]
+    assert "terminal_observation" in inf[3] and "terminal_observation" not in inf[0]
+    assert inf[-1]["food_collected"] == 4 and inf[2]["score"] == 20.0 and len(inf[1:3]) == 2
+
+
+def test_bench_roofline_accounting():
+    sys.path.insert(0, ROOT)
+    import bench
+    cfg = pkg.load_env_config("single_food_long_horizon")
+    assert bench.algorithmic_bytes_per_env_step(cfg, 1) == 218.0              # SURVEY.md §8d step-per-launch
+    assert abs(bench.algorithmic_bytes_per_env_step(cfg, 5000) - 106.0224) < 1e-9
+    assert bench.algorithmic_bytes_per_env_step(pkg.load_env_config("sac_gail"), 1) == 394.0

@@ -1,0 +1,104 @@
+"""Multi-process coverage of the env-index sharding + all-gather path (world_size 2, gloo, CPU).
+
+The per-rank simulator is injected: here it is the CPU oracle (test infrastructure), standing in
+for the HIP engine so that the sharding / global-index keying / gather logic of
+`ShardedSalpVectorEnv` runs without a GPU.  The product default engine is the HIP library."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as ol
+import underwater_swimmer_rl_amd as pkg
+from underwater_swimmer_rl_amd.sharded import ShardedSalpVectorEnv
+
+
+class OracleEngine:
+    """VectorEnv-shaped wrapper of the oracle with the HIP engine's call shapes."""
+
+    def __init__(self, cfg, n, seed, base):
+        self.o = ol.OracleVec(cfg, n, seed=seed, env_index_base=base)
+        self.num_envs = n
+
+    def reset(self, seed=None, options=None):
+        return self.o.reset(), {}
+
+    def step(self, actions):
+        out = self.o.step(np.asarray(actions, np.float32))
+        return out["obs"], out["reward"], out["terminated"].astype(bool), out["truncated"].astype(bool), {}
+
+    def rollout(self, actions=None, horizon=None):
+        a = None if actions is None else np.asarray(actions, np.float32)
+        return self.o.rollout(a, horizon=horizon)
+
+    def close(self):
+        self.o.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = pkg.load_env_config("sac_gail", max_steps_without_food=60)
+        N, H, seed = 64, 150, 5
+        rng = np.random.default_rng(0)
+        act = rng.uniform(-1, 1, size=(H, N, 1)).astype(np.float32)          # the same GLOBAL actions on every rank
+        env = ShardedSalpVectorEnv(cfg, N, seed=seed, engine_factory=lambda c, n, s, b: OracleEngine(c, n, s, b))
+        assert env.local_envs == N // world and env.env_index_base == rank * (N // world)
+        obs0, _ = env.reset()
+        obs0 = obs0.clone()                 # gathered tensors are reused buffers (valid until the next call)
+        steps = []
+        for t in range(40):
+            g_obs, g_rew, g_term, g_trunc, _ = env.step(torch.from_numpy(act[t]))
+            steps.append((g_obs.numpy().copy(), g_rew.numpy().copy(), g_term.numpy().copy(), g_trunc.numpy().copy()))
+        local, g_final = env.rollout(torch.from_numpy(act[40:]), gather="final")
+        _, g_all = env.rollout(torch.from_numpy(act[:10]), gather="all", async_gather=True)
+        env.wait_gather()
+        _, g_none = env.rollout(torch.from_numpy(act[:5]), gather="none")
+        assert g_none is None
+        np.savez(os.path.join(tmp, f"rank{rank}.npz"), obs0=obs0.numpy(), g_final=g_final.numpy(), g_all=g_all.numpy(),
+                 **{f"s{t}_{k}": v for t, s in enumerate(steps) for k, v in zip(("obs", "rew", "term", "trunc"), s)})
+        env.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharding_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    for k in r0.files:   # every rank holds the same gathered batch
+        assert np.array_equal(r0[k], r1[k], equal_nan=True), k
+    # and it equals one unsharded simulator over all 64 envs
+    cfg = pkg.load_env_config("sac_gail", max_steps_without_food=60)
+    N, H, seed = 64, 150, 5
+    act = np.random.default_rng(0).uniform(-1, 1, size=(H, N, 1)).astype(np.float32)
+    one = ol.OracleVec(cfg, N, seed=seed)
+    assert np.array_equal(r0["obs0"], one.reset())          # reset() draws new food, as snake:133-155 does
+    for t in range(40):
+        out = one.step(act[t])
+        assert np.array_equal(r0[f"s{t}_obs"], out["obs"]) and np.array_equal(r0[f"s{t}_rew"], out["reward"])
+        assert np.array_equal(r0[f"s{t}_term"], out["terminated"].astype(bool))
+        assert np.array_equal(r0[f"s{t}_trunc"], out["truncated"].astype(bool))
+    out = one.rollout(act[40:])
+    assert out["truncated"].sum() > 0                                         # resets happened inside the shard
+    assert np.array_equal(r0["g_final"], out["obs"][-1])
+    out = one.rollout(act[:10])
+    g_all = r0["g_all"]                                                      # [G, H, n_local, D]
+    assert g_all.shape == (2, 10, 32, cfg.obs_dim)
+    assert np.array_equal(np.concatenate([g_all[0], g_all[1]], axis=1), out["obs"])
