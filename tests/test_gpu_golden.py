@@ -1,0 +1,53 @@
+"""The HIP path (C ABI) against the golden vectors generated from the reference's own Python
+implementation (tests/golden/ref_*.npz): flags and info integers identical, observations within
+1e-5 (angle columns on the circle), rewards within 1e-5 * max(1, |r|), fp64 end state within 1e-9."""
+import numpy as np
+import pytest
+
+from golden_util import fixture_names, load_fixture, obs_diff
+from underwater_swimmer_rl_amd import _capi
+from underwater_swimmer_rl_amd._capi import SalpLib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_hip_matches_reference_vectors(name):
+    z, meta, cfg = load_fixture(name)
+    act = np.ascontiguousarray(z["actions"])
+    H, n, _ = act.shape
+    dev = SalpLib(cfg, n, device_id=0, seed=meta["seed"], env_index_base=meta["env_index_base"])
+    if "inject_f64" in z.files:
+        dev.set_state(np.ascontiguousarray(z["inject_f64"]), np.ascontiguousarray(z["inject_i32"]), 0)
+    obs0 = np.empty((n, cfg.obs_dim), np.float32)
+    dev.observe(obs0, 0)
+    assert obs_diff(cfg, obs0, z["reset_obs"]).max() <= 1e-5
+    obs = np.empty((H, n, cfg.obs_dim), np.float32)
+    fin = np.full((H, n, cfg.obs_dim), np.nan, np.float32)
+    rew = np.empty((H, n), np.float32)
+    term = np.empty((H, n), np.uint8)
+    trunc = np.empty((H, n), np.uint8)
+    info = np.empty((n, 3), np.int32)
+    # step-by-step through salp_vec_step (info + final_obs), the reference's own call shape
+    for t in range(H):
+        dev.step(act[t], obs[t], rew[t], term[t], trunc[t], fin[t], info, 0)
+        assert np.array_equal(info, z["info"][t]), f"info at step {t}"
+    assert np.array_equal(term, z["terminated"]) and np.array_equal(trunc, z["truncated"])
+    nan_ref = np.isnan(z["obs"])
+    assert np.array_equal(np.isnan(obs), nan_ref)
+    assert obs_diff(cfg, obs, z["obs"]).max() <= 1e-5
+    done = (z["terminated"] | z["truncated"]).astype(bool)
+    assert np.array_equal(~np.isnan(fin[..., 0]), done)      # terminal rows are written for finished envs only
+    if done.any():
+        assert obs_diff(cfg, fin[done], z["final_obs"][done]).max() <= 1e-5
+    r = z["reward"]
+    ok = np.isfinite(r)
+    assert (np.abs(rew[ok] - r[ok]) / np.maximum(1.0, np.abs(r[ok]))).max() <= 1e-5
+    f64 = np.empty((_capi.F_FOOD0 + 2 * cfg.num_food_items, n), np.float64)
+    i32 = np.empty((_capi.I_COUNT, n), np.int32)
+    dev.get_state(f64, i32, 0)
+    assert np.array_equal(i32, z["end_i32"]), np.nonzero(i32 != z["end_i32"])
+    e = z["end_f64"]
+    assert np.array_equal(np.isnan(f64), np.isnan(e))
+    assert np.nanmax(np.abs(f64 - e)) <= 1e-9
+    dev.close()
