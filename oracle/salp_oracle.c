@@ -278,18 +278,18 @@ static void respawn_food(const struct salp_oracle* h, int64_t i, env_t* e) {
 }
 
 /* snake:157-202 step over legacy:119-156 step. Returns reward; sets flags. */
-static double step_env(const struct salp_oracle* h, int64_t i, env_t* e, const float* act,
+static double step_env(const struct salp_oracle* h, int64_t i, env_t* e, const double* act,
                        int* terminated, int* truncated, int* collision_out) {
   const salp_config_t* c = &h->cfg;
   /* legacy:121-135 action decode */
   double nozzle_direction;
   if (c->forced_breathing) {
-    nozzle_direction = (double)act[0];
+    nozzle_direction = act[0];
     int cycle = c->inhale_duration + c->exhale_duration + c->rest_duration; /* legacy:158-167 */
     e->is_inhaling = (e->timer % cycle) < c->inhale_duration;
   } else {
-    double inhale_control = (double)act[0];
-    nozzle_direction = (double)act[1];
+    double inhale_control = act[0];
+    nozzle_direction = act[1];
     e->is_inhaling = inhale_control > 0.5;
   }
   e->target_nozzle = nozzle_direction * c->max_nozzle_angle;
@@ -487,7 +487,7 @@ static float device_action(const salp_oracle_t* h, int64_t i, int64_t t, int j, 
   return (float)(w[0] >> 8) * 1.1920928955078125e-7f - 1.0f;                      /* [-1,1) */
 }
 
-int salp_oracle_rollout(salp_oracle_t* h, const float* act, int32_t horizon, float* obs,
+static int rollout_impl(salp_oracle_t* h, const float* act, const double* act64, int32_t horizon, float* obs,
                         float* reward, double* reward64, uint8_t* terminated, uint8_t* truncated,
                         float* final_obs, int32_t* info, float* act_out) {
   const int od = salp_oracle_obs_dim(h), ad = salp_oracle_act_dim(h);
@@ -498,11 +498,15 @@ int salp_oracle_rollout(salp_oracle_t* h, const float* act, int32_t horizon, flo
     env_t* e = &h->env[i];
     for (int32_t t = 0; t < horizon; ++t) {
       const int64_t row = (int64_t)t * n + i;
-      float a[2];
-      if (act) { for (int j = 0; j < ad; ++j) a[j] = act[row * ad + j]; }
+      double a[2];
+      if (act64) { for (int j = 0; j < ad; ++j) a[j] = act64[row * ad + j]; }
+      else if (act) { for (int j = 0; j < ad; ++j) a[j] = (double)act[row * ad + j]; } /* float(action[j]) */
       else {
-        for (int j = 0; j < ad; ++j) a[j] = device_action(h, i, t0 + t, j, ad);
-        if (act_out) for (int j = 0; j < ad; ++j) act_out[row * ad + j] = a[j];
+        for (int j = 0; j < ad; ++j) {
+          float g = device_action(h, i, t0 + t, j, ad);
+          a[j] = (double)g;
+          if (act_out) act_out[row * ad + j] = g;
+        }
       }
       int term, trunc, coll;
       double r = step_env(h, i, e, a, &term, &trunc, &coll);
@@ -524,6 +528,19 @@ int salp_oracle_rollout(salp_oracle_t* h, const float* act, int32_t horizon, flo
   }
   h->global_step += horizon;
   return 0;
+}
+
+int salp_oracle_rollout(salp_oracle_t* h, const float* act, int32_t horizon, float* obs,
+                        float* reward, double* reward64, uint8_t* terminated, uint8_t* truncated,
+                        float* final_obs, int32_t* info, float* act_out) {
+  return rollout_impl(h, act, NULL, horizon, obs, reward, reward64, terminated, truncated, final_obs, info, act_out);
+}
+
+/* fp64 actions, as the reference's human-demo recorder passed them (legacy:125 float(action[0])). */
+int salp_oracle_rollout_f64(salp_oracle_t* h, const double* act64, int32_t horizon, float* obs,
+                            double* reward64, uint8_t* terminated, uint8_t* truncated) {
+  if (!act64) return -1;
+  return rollout_impl(h, NULL, act64, horizon, obs, NULL, reward64, terminated, truncated, NULL, NULL, NULL);
 }
 
 int salp_oracle_step(salp_oracle_t* h, const float* act, float* obs, float* reward,

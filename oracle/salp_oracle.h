@@ -30,6 +30,9 @@ int salp_oracle_step(salp_oracle_t* h, const float* act, float* obs, float* rewa
 int salp_oracle_rollout(salp_oracle_t* h, const float* act, int32_t horizon, float* obs,
                         float* reward, double* reward64, uint8_t* terminated, uint8_t* truncated,
                         float* final_obs, int32_t* info, float* act_out);
+/* test-only variant with fp64 actions (the reference accepts any float; the product ABI is f32) */
+int salp_oracle_rollout_f64(salp_oracle_t* h, const double* act64, int32_t horizon, float* obs,
+                            double* reward64, uint8_t* terminated, uint8_t* truncated);
 int salp_oracle_get_state(salp_oracle_t* h, double* f64, int32_t* i32);
 int salp_oracle_set_state(salp_oracle_t* h, const double* f64, const int32_t* i32);
 int64_t salp_oracle_global_step(const salp_oracle_t* h);

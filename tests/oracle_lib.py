@@ -44,6 +44,7 @@ def lib():
         L.salp_oracle_observe.argtypes = [vp, vp]
         L.salp_oracle_step.argtypes = [vp] * 9
         L.salp_oracle_rollout.argtypes = [vp, vp, i32] + [vp] * 8
+        L.salp_oracle_rollout_f64.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         L.salp_oracle_get_state.argtypes = [vp, vp, vp]
         L.salp_oracle_set_state.argtypes = [vp, vp, vp]
         L.salp_oracle_set_threads.argtypes = [ctypes.c_int]
@@ -134,6 +135,19 @@ class OracleVec:
             raise RuntimeError(f"salp_oracle_rollout failed: {rc}")
         return dict(obs=obs, reward=reward, reward64=r64, terminated=term, truncated=trunc,
                     final_obs=fin, info=info, actions=aout)
+
+    def rollout_f64(self, act64):
+        """fp64 actions [H, n, act_dim] (test-only entry point, see oracle/salp_oracle.h)."""
+        a = np.ascontiguousarray(act64, dtype=np.float64).reshape(-1, self.n, self.act_dim)
+        H = a.shape[0]
+        obs = np.empty((H, self.n, self.obs_dim), np.float32)
+        r64 = np.empty((H, self.n), np.float64)
+        term = np.empty((H, self.n), np.uint8)
+        trunc = np.empty((H, self.n), np.uint8)
+        rc = lib().salp_oracle_rollout_f64(self._h, _p(a), H, _p(obs), _p(r64), _p(term), _p(trunc))
+        if rc != 0:
+            raise RuntimeError(f"salp_oracle_rollout_f64 failed: {rc}")
+        return dict(obs=obs, reward64=r64, terminated=term, truncated=trunc)
 
     def get_state(self):
         f64 = np.empty((F_FOOD0 + 2 * self.F, self.n), np.float64)
