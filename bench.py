@@ -113,14 +113,21 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # SALP_BENCH_FORCE_SHARDED=1 runs the sharded (RCCL) code path at world size 1 — a rehearsal of the
+    # multi-GPU path on a one-GPU box; the reported numbers are then those of that path.
+    force_sharded = world == 1 and os.environ.get("SALP_BENCH_FORCE_SHARDED") == "1"
+    if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if force_sharded:
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     cfg = pkg.load_env_config(args.preset)
     n, H, K, W = args.envs, args.chunk, args.steps, args.warmup
 
-    if world > 1:
+    if world > 1 or force_sharded:
         from underwater_swimmer_rl_amd.sharded import ShardedSalpVectorEnv
         senv = ShardedSalpVectorEnv(cfg, n * world, device=f"cuda:{local_rank}", seed=0)
         env = senv.engine
@@ -147,7 +154,7 @@ def main():
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
     torch.cuda.synchronize(device)
-    if world > 1:
+    if senv is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -170,13 +177,13 @@ def main():
     if senv is not None:
         senv.wait_gather()
     torch.cuda.synchronize(device)
-    if world > 1:
+    if senv is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
 
     el_t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if senv is not None:
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
     elapsed = float(el_t.item())
     kernel_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
@@ -208,7 +215,7 @@ def main():
         "config": {
             "workload": f"BASELINE configs[2]: N_envs={n}/GPU {args.preset}, {H * K}-step rollout as {K} fused launches of {H} steps, random actions in HBM",
             "envs_per_gpu": n, "chunk": H, "obs_dim": cfg.obs_dim, "act_dim": cfg.act_dim,
-            "parallelism": f"env-sharded x{world}" + (f", all-gather {args.gather} obs" if world > 1 else ""),
+            "parallelism": f"env-sharded x{world}" + (f", all-gather {args.gather} obs" if senv is not None else ""),
             "env_steps_per_bench_step": n * H * world,
         },
         "roofline": {

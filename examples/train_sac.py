@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: SAC (configs/sac_gail.yaml agent block) with a PyTorch-ROCm policy on the HIP
+VectorEnv; reports the wall-clock to the first food capture.  One GPU:
+    python examples/train_sac.py --envs 4096 --steps 2000
+Multi-GPU data-parallel training is out of this round's scope."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import underwater_swimmer_rl_amd as salp
+from underwater_swimmer_rl_amd.sac import SAC, SACConfig, train_sac
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", default="sac_gail")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=2000, help="vector env steps")
+    ap.add_argument("--learning-starts", type=int, default=50)
+    ap.add_argument("--updates-per-step", type=int, default=1)
+    ap.add_argument("--stop-at-first-food", action="store_true")
+    ap.add_argument("--log-every", type=int, default=200)
+    args = ap.parse_args()
+    env = salp.SalpVectorEnv(args.preset, num_envs=args.envs, device="cuda:0", seed=0)
+    cfg = SACConfig.from_preset(args.preset)
+    cfg.learning_starts, cfg.updates_per_step = args.learning_starts, args.updates_per_step
+    agent = SAC(env.obs_dim, env.act_dim, cfg, device="cuda:0", seed=0,
+                act_low=env.single_action_space.low, act_high=env.single_action_space.high)
+    m = train_sac(env, agent, args.steps, log_every=args.log_every, stop_at_first_food=args.stop_at_first_food)
+    m["stats"] = env.stats()
+    m["config"] = {"preset": args.preset, "envs": args.envs, "batch_size": cfg.batch_size, "gamma": cfg.gamma}
+    print(json.dumps(m))
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""The learner side: SAC with SB3's MlpPolicy architecture and the GAIL
+discriminator, on device tensors.  CPU tests check shapes / maths on tiny problems; the GPU test
+runs the learner against the HIP vector env."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import underwater_swimmer_rl_amd as pkg
+from underwater_swimmer_rl_amd.gail import Discriminator, ExpertBuffer, gail_reward_fn
+from underwater_swimmer_rl_amd.sac import SAC, Actor, DeviceReplayBuffer, SACConfig, TwinQ, train_sac
+
+
+def test_actor_matches_sb3_mlp_policy_shapes_and_squashing():
+    torch.manual_seed(0)
+    a = Actor(24, 2, (256, 256), act_low=[0.0, -1.0], act_high=[1.0, 1.0])
+    assert sum(p.numel() for p in a.parameters()) == 24 * 256 + 256 + 256 * 256 + 256 + 2 * (256 * 2 + 2)
+    act, logp = a(torch.randn(512, 24))
+    assert act.shape == (512, 2) and logp.shape == (512,)
+    assert act[:, 0].min() >= 0.0 and act[:, 0].max() <= 1.0 and act[:, 1].abs().max() <= 1.0
+    # log-prob of the squashed Gaussian agrees with the direct formula
+    obs = torch.randn(64, 24)
+    torch.manual_seed(1)
+    act, logp = a(obs)
+    h = a.body(obs)
+    mu, ls = a.mu(h), a.log_std(h).clamp(-20, 2)
+    u = torch.atanh(a.unscale(act).clamp(-1 + 1e-6, 1 - 1e-6))
+    direct = torch.distributions.Normal(mu, ls.exp()).log_prob(u).sum(-1) - torch.log(1 - torch.tanh(u) ** 2 + 1e-6).sum(-1)
+    assert torch.allclose(logp, direct, atol=2e-3)
+    q = TwinQ(24, 2)
+    q1, q2 = q(obs, act)
+    assert q1.shape == (64,) and q2.shape == (64,)
+
+
+def test_replay_buffer_ring_semantics():
+    buf = DeviceReplayBuffer(10, 3, 1, "cpu")
+    for k in range(4):
+        n = 4
+        o = torch.full((n, 3), float(k))
+        buf.add(o, torch.zeros(n, 1), torch.full((n,), float(k)), o + 1, torch.zeros(n, dtype=torch.bool))
+    assert buf.size == 10 and buf.pos == 6
+    assert set(buf.rew.tolist()) == {1.0, 2.0, 3.0}      # the oldest rows (k = 0) were overwritten
+    o, a, r, no, t = buf.sample(32)
+    assert o.shape == (32, 3) and torch.equal(no, o + 1)
+
+
+def test_sac_learns_a_one_step_bandit():
+    """Reward = -(a - 0.5)^2: the squashed policy mean must move to 0.5."""
+    torch.manual_seed(0)
+    cfg = SACConfig(hidden_sizes=(32, 32), batch_size=256, alpha=0.01, learning_rate=3e-3)
+    agent = SAC(4, 1, cfg, device="cpu")
+    buf = DeviceReplayBuffer(4096, 4, 1, "cpu")
+    obs = torch.zeros(4096, 4)
+    act = torch.rand(4096, 1) * 2 - 1
+    buf.add(obs, act, -(act[:, 0] - 0.5) ** 2, obs, torch.ones(4096, dtype=torch.bool))
+    for _ in range(400):
+        m = agent.update(buf.sample(cfg.batch_size))
+    a = agent.act(torch.zeros(1, 4), deterministic=True)
+    assert abs(float(a) - 0.5) < 0.15, float(a)
+    assert math.isfinite(float(m["critic_loss"]))
+    sd = agent.state_dict()
+    other = SAC(4, 1, cfg, device="cpu")
+    other.load_state_dict(sd)
+    assert torch.equal(other.act(torch.zeros(1, 4), deterministic=True), a)
+
+
+def test_discriminator_separates_expert_from_agent_and_rewards_follow():
+    torch.manual_seed(0)
+    d = Discriminator(6, 1, (32, 32), learning_rate=3e-3, device="cpu")
+    eb = ExpertBuffer(6, 1, device="cpu")
+    eo = np.random.default_rng(0).normal(1.0, 0.3, size=(500, 6)).astype(np.float32)
+    eb.add_episode(eo, np.full((500, 1), 0.8, np.float32))
+    assert len(eb) == 500 and eb.episodes == 1
+    for _ in range(300):
+        agent_batch = {"observations": torch.randn(64, 6) * 0.3 - 1.0, "actions": torch.full((64, 1), -0.8)}
+        m = d.update(eb.sample(64), agent_batch)
+    assert m["discriminator_accuracy"] > 0.95
+    r_exp = d.predict_reward(torch.full((8, 6), 1.0), torch.full((8, 1), 0.8))
+    r_agt = d.predict_reward(torch.full((8, 6), -1.0), torch.full((8, 1), -0.8))
+    assert r_exp.shape == (8,) and float(r_exp.mean()) > float(r_agt.mean()) + 1.0
+    mix = gail_reward_fn(d)(torch.full((8, 6), 1.0), torch.full((8, 1), 0.8), torch.ones(8))
+    assert torch.allclose(mix, 0.3 * torch.ones(8) + 0.7 * r_exp)
+
+
+def test_agent_presets_restate_the_yaml_agent_blocks():
+    c = SACConfig.from_preset("single_food_long_horizon")
+    assert (c.batch_size, c.buffer_size, c.gamma, c.alpha, c.target_entropy) == (256, 100_000, 0.995, 0.2, -0.5)
+    assert SACConfig.from_preset("sac_gail").alpha == 0.1
+
+
+@pytest.mark.gpu
+def test_sac_trains_on_the_hip_vector_env():
+    """configs[4] plumbing: SAC (sac_gail.yaml agent block) on the HIP VectorEnv, GAIL reward mixed in."""
+    env = pkg.SalpVectorEnv("sac_gail", num_envs=1024, device="cuda:0", seed=0)
+    cfg = SACConfig.from_preset("sac_gail")
+    cfg.learning_starts, cfg.updates_per_step = 20, 2
+    agent = SAC(env.obs_dim, env.act_dim, cfg, device="cuda:0", seed=0)
+    disc = Discriminator(env.obs_dim, env.act_dim, device="cuda:0")
+    eb = ExpertBuffer(env.obs_dim, env.act_dim, device="cuda:0")
+    eb.add_episode(np.random.default_rng(0).uniform(-1, 1, (256, env.obs_dim)), np.zeros((256, env.act_dim)))
+    m = train_sac(env, agent, total_vector_steps=60, reward_fn=gail_reward_fn(disc))
+    assert m["env_steps"] == 60 * 1024 and m["updates"] == 80
+    assert all(math.isfinite(m[k]) for k in ("critic_loss", "actor_loss", "alpha"))
+    d = disc.update(eb.sample(128), {"observations": env.observe().clone(), "actions": agent.act(env.observe())})
+    assert math.isfinite(d["discriminator_loss"])
+    env.close()

@@ -181,6 +181,15 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
     if (FULL || io.obs) {
       float ob[12 + 4 * KMAX];
       observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
+#ifdef SALP_EXP_DIRECT_STORE   // experiment: per-lane 96-B rows straight from registers (no LDS transpose)
+      if (active) {
+        float4* drow = reinterpret_cast<float4*>(io.obs + (rowbase + env) * OD);
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q)
+          if (q < Q) drow[q] = make_float4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
+      }
+      if (rows < 0)
+#endif
 #pragma unroll
       for (int q = 0; q < QMAX; ++q)   // 16-B LDS stores at a 16-B-padded pitch: conflict-free
         if (q < Q) myrow4[q] = make_float4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);

@@ -1,0 +1,275 @@
+"""Soft Actor-Critic on PyTorch-ROCm, consuming the batched simulator's device tensors
+(BASELINE.json configs[4]).
+
+The reference trains with stable-baselines3 `SAC("MlpPolicy", env, ...)` (train.py:60-70;
+src/salp/agents/sb3_sac_agent.py:66-90), which is not vendored and cannot keep up with thousands of
+envs (per-env Python info dicts, row-wise replay inserts).  This module restates that learner with
+SB3's MlpPolicy architecture and defaults — actor obs→256→256→(mean, log_std) with tanh squashing
+and log_std clamped to [-20, 2]; twin critics (obs, act)→256→256→1, ReLU; Adam 3e-4; polyak tau;
+automatic entropy tuning with target entropy −|A| unless the YAML's `alpha` / `target_entropy`
+are given (sb3_sac_agent.py:77-79) — on tensors that never leave the GPU: the replay buffer is a
+set of device tensors filled N rows per env step.
+
+Pure PyTorch (the policy nets are the one place the north_star assigns to PyTorch-ROCm); the
+environment stepping goes through the HIP library.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import time
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+LOG_STD_MIN, LOG_STD_MAX = -20.0, 2.0   # stable_baselines3.sac.policies
+
+
+def mlp(sizes: Sequence[int], out_dim: int) -> nn.Sequential:
+    layers, d = [], sizes[0]
+    for h in sizes[1:]:
+        layers += [nn.Linear(d, h), nn.ReLU()]
+        d = h
+    layers.append(nn.Linear(d, out_dim))
+    return nn.Sequential(*layers)
+
+
+class Actor(nn.Module):
+    def __init__(self, obs_dim, act_dim, hidden=(256, 256), act_low=None, act_high=None):
+        super().__init__()
+        body, d = [], obs_dim
+        for h in hidden:
+            body += [nn.Linear(d, h), nn.ReLU()]
+            d = h
+        self.body = nn.Sequential(*body)
+        self.mu = nn.Linear(d, act_dim)
+        self.log_std = nn.Linear(d, act_dim)
+        low = torch.full((act_dim,), -1.0) if act_low is None else torch.as_tensor(act_low, dtype=torch.float32)
+        high = torch.full((act_dim,), 1.0) if act_high is None else torch.as_tensor(act_high, dtype=torch.float32)
+        # SB3 squashes to [-1, 1] and rescales to the Box bounds (snake:69-74: [-1,1] or [0,1]x[-1,1])
+        self.register_buffer("scale", (high - low) / 2)
+        self.register_buffer("shift", (high + low) / 2)
+
+    def forward(self, obs, deterministic=False, with_logprob=True):
+        h = self.body(obs)
+        mu, log_std = self.mu(h), self.log_std(h).clamp(LOG_STD_MIN, LOG_STD_MAX)
+        std = log_std.exp()
+        u = mu if deterministic else mu + std * torch.randn_like(mu)
+        a = torch.tanh(u)
+        logp = None
+        if with_logprob:
+            # log N(u; mu, std) - sum log(1 - tanh(u)^2), the numerically stable form
+            logp = (-0.5 * ((u - mu) / std) ** 2 - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+            logp = logp - (2 * (math.log(2) - u - F.softplus(-2 * u))).sum(-1)
+        return a * self.scale + self.shift, logp
+
+    def unscale(self, action):
+        return (action - self.shift) / self.scale
+
+
+class TwinQ(nn.Module):
+    def __init__(self, obs_dim, act_dim, hidden=(256, 256)):
+        super().__init__()
+        self.q1 = mlp([obs_dim + act_dim, *hidden], 1)
+        self.q2 = mlp([obs_dim + act_dim, *hidden], 1)
+
+    def forward(self, obs, act):
+        x = torch.cat([obs, act], dim=-1)
+        return self.q1(x).squeeze(-1), self.q2(x).squeeze(-1)
+
+
+class DeviceReplayBuffer:
+    """Ring buffer of transitions as device tensors; `add` takes N rows at once."""
+
+    def __init__(self, capacity, obs_dim, act_dim, device):
+        self.capacity, self.device = int(capacity), device
+        self.obs = torch.empty((self.capacity, obs_dim), device=device)
+        self.next_obs = torch.empty((self.capacity, obs_dim), device=device)
+        self.act = torch.empty((self.capacity, act_dim), device=device)
+        self.rew = torch.empty((self.capacity,), device=device)
+        self.term = torch.empty((self.capacity,), device=device)   # 1.0 where the episode TERMINATED (no bootstrap)
+        self.pos, self.size = 0, 0
+
+    @torch.no_grad()
+    def add(self, obs, act, rew, next_obs, terminated):
+        n = obs.shape[0]
+        if n >= self.capacity:
+            obs, act, rew, next_obs, terminated = (t[-self.capacity:] for t in (obs, act, rew, next_obs, terminated))
+            n = self.capacity
+        end = self.pos + n
+        if end <= self.capacity:
+            sl = slice(self.pos, end)
+            self.obs[sl], self.act[sl], self.rew[sl], self.next_obs[sl] = obs, act, rew, next_obs
+            self.term[sl] = terminated.to(self.rew.dtype)
+        else:
+            k = self.capacity - self.pos
+            self.add(obs[:k], act[:k], rew[:k], next_obs[:k], terminated[:k])
+            self.add(obs[k:], act[k:], rew[k:], next_obs[k:], terminated[k:])
+            return
+        self.pos = end % self.capacity
+        self.size = min(self.capacity, self.size + n)
+
+    def sample(self, batch_size, generator=None):
+        idx = torch.randint(0, self.size, (batch_size,), device=self.device, generator=generator)
+        return self.obs[idx], self.act[idx], self.rew[idx], self.next_obs[idx], self.term[idx]
+
+
+@dataclasses.dataclass
+class SACConfig:
+    """`agent:` block of the reference's YAML presets (configs/*.yaml)."""
+    hidden_sizes: Sequence[int] = (256, 256)
+    learning_rate: float = 3e-4
+    batch_size: int = 128
+    buffer_size: int = 500_000
+    gamma: float = 0.99
+    tau: float = 0.005
+    alpha: Optional[float] = None            # None = learned ("auto", SB3 default); else fixed
+    target_entropy: Optional[float] = None   # None = -act_dim
+    alpha_lr: float = 3e-4
+    learning_starts: int = 1000              # env-steps (per env) of random actions before updates
+    updates_per_step: int = 1                # gradient steps per vector env step
+
+    @classmethod
+    def from_preset(cls, name: str) -> "SACConfig":
+        p = AGENT_PRESETS[name]
+        return cls(**p)
+
+
+# `agent:` blocks of configs/single_food.yaml:20-33, single_food_long_horizon.yaml:20-33, sac_gail.yaml:16-29
+AGENT_PRESETS: Dict[str, dict] = {
+    "single_food": dict(batch_size=128, buffer_size=500_000, gamma=0.99, tau=0.005, alpha=0.5, target_entropy=-0.5),
+    "single_food_long_horizon": dict(batch_size=256, buffer_size=100_000, gamma=0.995, tau=0.005, alpha=0.2,
+                                     target_entropy=-0.5),
+    "sac_gail": dict(batch_size=128, buffer_size=500_000, gamma=0.99, tau=0.005, alpha=0.1, target_entropy=-1.0),
+}
+
+
+class SAC:
+    def __init__(self, obs_dim, act_dim, cfg: SACConfig = SACConfig(), device="cuda", act_low=None, act_high=None,
+                 learn_alpha: Optional[bool] = None, seed: Optional[int] = None):
+        self.cfg, self.device = cfg, torch.device(device)
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.actor = Actor(obs_dim, act_dim, cfg.hidden_sizes, act_low, act_high).to(self.device)
+        self.critic = TwinQ(obs_dim, act_dim, cfg.hidden_sizes).to(self.device)
+        self.critic_target = TwinQ(obs_dim, act_dim, cfg.hidden_sizes).to(self.device)
+        self.critic_target.load_state_dict(self.critic.state_dict())
+        for p in self.critic_target.parameters():
+            p.requires_grad_(False)
+        self.actor_opt = torch.optim.Adam(self.actor.parameters(), lr=cfg.learning_rate)
+        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=cfg.learning_rate)
+        # train.py:60-70 leaves ent_coef at SB3's "auto"; SB3SACAgent passes the YAML alpha (fixed)
+        self.learn_alpha = (cfg.alpha is None) if learn_alpha is None else learn_alpha
+        init_alpha = 1.0 if cfg.alpha is None else float(cfg.alpha)
+        self.log_alpha = torch.tensor(math.log(init_alpha), device=self.device, requires_grad=self.learn_alpha)
+        self.alpha_opt = torch.optim.Adam([self.log_alpha], lr=cfg.alpha_lr) if self.learn_alpha else None
+        self.target_entropy = -float(act_dim) if cfg.target_entropy is None else float(cfg.target_entropy)
+        self.updates = 0
+
+    @torch.no_grad()
+    def act(self, obs, deterministic=False):
+        a, _ = self.actor(obs, deterministic=deterministic, with_logprob=False)
+        return a
+
+    def update(self, batch) -> Dict[str, torch.Tensor]:
+        obs, act, rew, next_obs, term = batch
+        alpha = self.log_alpha.exp().detach()
+        with torch.no_grad():
+            na, nlogp = self.actor(next_obs)
+            tq1, tq2 = self.critic_target(next_obs, na)
+            target = rew + self.cfg.gamma * (1.0 - term) * (torch.min(tq1, tq2) - alpha * nlogp)
+        q1, q2 = self.critic(obs, act)
+        critic_loss = 0.5 * (F.mse_loss(q1, target) + F.mse_loss(q2, target))
+        self.critic_opt.zero_grad(set_to_none=True)
+        critic_loss.backward()
+        self.critic_opt.step()
+
+        pa, logp = self.actor(obs)
+        pq1, pq2 = self.critic(obs, pa)
+        actor_loss = (alpha * logp - torch.min(pq1, pq2)).mean()
+        self.actor_opt.zero_grad(set_to_none=True)
+        actor_loss.backward()
+        self.actor_opt.step()
+
+        if self.learn_alpha:
+            alpha_loss = -(self.log_alpha * (logp.detach() + self.target_entropy).mean())
+            self.alpha_opt.zero_grad(set_to_none=True)
+            alpha_loss.backward()
+            self.alpha_opt.step()
+        with torch.no_grad():  # polyak update (core/base_agent.py:63-74 soft_update)
+            for p, tp in zip(self.critic.parameters(), self.critic_target.parameters()):
+                tp.mul_(1.0 - self.cfg.tau).add_(p, alpha=self.cfg.tau)
+        self.updates += 1
+        return {"critic_loss": critic_loss.detach(), "actor_loss": actor_loss.detach(),
+                "alpha": self.log_alpha.exp().detach(), "entropy": -logp.detach().mean()}
+
+    def state_dict(self):
+        return {"actor": self.actor.state_dict(), "critic": self.critic.state_dict(),
+                "critic_target": self.critic_target.state_dict(), "log_alpha": self.log_alpha.detach().clone()}
+
+    def load_state_dict(self, sd):
+        self.actor.load_state_dict(sd["actor"])
+        self.critic.load_state_dict(sd["critic"])
+        self.critic_target.load_state_dict(sd["critic_target"])
+        with torch.no_grad():
+            self.log_alpha.copy_(sd["log_alpha"])
+
+
+def train_sac(env, agent: SAC, total_vector_steps: int, buffer: Optional[DeviceReplayBuffer] = None,
+              reward_fn=None, log_every: int = 0, stop_at_first_food: bool = False) -> Dict[str, float]:
+    """Collect with the vector env, learn from the device replay buffer.
+
+    env: SalpVectorEnv(output="torch") (or anything with its step/reset surface returning device
+    tensors).  `reward_fn(obs, act, env_reward)` lets a GAIL discriminator mix its reward in
+    (configs/sac_gail.yaml:44-45).  Returns timing / progress metrics, including the wall-clock to
+    the first food capture of any env (BASELINE.json configs[4])."""
+    cfg, dev = agent.cfg, agent.device
+    n = env.num_envs
+    buffer = buffer or DeviceReplayBuffer(cfg.buffer_size, env.obs_dim, env.act_dim, dev)
+    low = torch.as_tensor(env.single_action_space.low, device=dev)
+    high = torch.as_tensor(env.single_action_space.high, device=dev)
+    obs, _ = env.reset()
+    obs = obs.clone()
+    t0 = time.perf_counter()
+    first_food_s, first_food_step = None, None
+    ep_returns = torch.zeros(n, device=dev)
+    finished_returns, finished = 0.0, 0
+    last = {}
+    for step in range(total_vector_steps):
+        if step < cfg.learning_starts:
+            act = low + (high - low) * torch.rand((n, env.act_dim), device=dev)
+        else:
+            act = agent.act(obs)
+        nobs, rew, term, trunc, info = env.step(act)
+        done = term | trunc
+        next_obs = torch.where(done[:, None], info["final_observation"], nobs)
+        r = rew if reward_fn is None else reward_fn(obs, act, rew)
+        buffer.add(obs, act, r, next_obs, term)
+        ep_returns += rew
+        if done.any():
+            finished_returns += float(ep_returns[done].sum())
+            finished += int(done.sum())
+            ep_returns[done] = 0.0
+        if first_food_s is None and bool((info["food_collected"] > 0).any()):
+            torch.cuda.synchronize() if dev.type == "cuda" else None
+            first_food_s, first_food_step = time.perf_counter() - t0, step + 1
+            if stop_at_first_food:
+                obs = nobs.clone()
+                break
+        obs = nobs.clone()
+        if step >= cfg.learning_starts and buffer.size >= cfg.batch_size:
+            for _ in range(cfg.updates_per_step):
+                last = agent.update(buffer.sample(cfg.batch_size))
+        if log_every and (step + 1) % log_every == 0:
+            msg = {k: float(v) for k, v in last.items()}
+            print(f"[sac] step {step + 1} env-steps {(step + 1) * n} updates {agent.updates} "
+                  f"episodes {finished} mean return {finished_returns / max(finished, 1):.2f} {msg}", flush=True)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {"wall_s": wall, "vector_steps": step + 1, "env_steps": (step + 1) * n, "updates": agent.updates,
+            "first_food_wall_s": first_food_s, "first_food_vector_step": first_food_step,
+            "episodes": finished, "mean_return": finished_returns / max(finished, 1),
+            **{k: float(v) for k, v in last.items()}}
