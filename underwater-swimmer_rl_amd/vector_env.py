@@ -115,6 +115,7 @@ class SalpVectorEnv:
             self._lib.close()
             self.seed_value = int(seed)
             self._lib = SalpLib(self.cfg, self.num_envs, self._device_index, self.seed_value, self.env_index_base)
+            self._step_cache = None
             obs = self._buf("obs", (self.num_envs, self.obs_dim), np.float32)
             self._lib.observe(obs, self._flags, self._stream)
             return obs, {}
@@ -128,28 +129,60 @@ class SalpVectorEnv:
         self._lib.reset(m, obs, self._flags, self._stream)
         return obs, {}
 
-    def step(self, actions, want_final_observation: bool = True):
+    def _prepare_step(self):
+        """Allocates the step outputs once and caches their raw pointers (the per-call cost of
+        `step` is then one ctypes call: at H = 1 the host, not the kernel, is the bottleneck)."""
+        import ctypes
         n = self.num_envs
-        a = self._actions_in(actions, (n,))
         obs = self._buf("obs", (n, self.obs_dim), np.float32)
         rew = self._buf("reward", (n,), np.float32)
         term = self._buf("terminated", (n,), np.uint8)
         trunc = self._buf("truncated", (n,), np.uint8)
         info_i = self._buf("info", (n, _capi.INFO_COLS), np.int32)
-        fin = self._buf("final_obs", (n, self.obs_dim), np.float32) if want_final_observation else None
-        self._lib.step(a, obs, rew, term, trunc, fin, info_i, self._flags, self._stream)
+        fin = self._buf("final_obs", (n, self.obs_dim), np.float32)
+        ptr = (lambda t: ctypes.c_void_p(t.data_ptr())) if self._torch is not None else \
+              (lambda a: a.ctypes.data_as(ctypes.c_void_p))
         if self._torch is not None:
-            terminated, truncated = term.bool(), trunc.bool()
+            term_b, trunc_b = term.view(self._torch.bool), trunc.view(self._torch.bool)   # zero-copy 0/1 bytes
+            done = self._torch.empty((n,), dtype=self._torch.bool, device=self.device)
         else:
-            terminated, truncated = term.astype(bool), trunc.astype(bool)
-        info = {
-            "food_collected": info_i[:, 0], "steps_since_food": info_i[:, 1], "collision": info_i[:, 2],
-            "score": info_i[:, 0] * float(self.cfg.food_reward),
-        }
-        if fin is not None:
-            info["final_observation"] = fin
-            info["_final_observation"] = terminated | truncated
-        return obs, rew, terminated, truncated, info
+            term_b, trunc_b = term.view(np.bool_), trunc.view(np.bool_)
+            done = np.empty((n,), dtype=np.bool_)
+        info = {"food_collected": info_i[:, 0], "steps_since_food": info_i[:, 1], "collision": info_i[:, 2],
+                "final_observation": fin, "_final_observation": done}
+        self._step_cache = dict(obs=obs, rew=rew, term=term_b, trunc=trunc_b, info=info, done=done,
+                                p_obs=ptr(obs), p_rew=ptr(rew), p_term=ptr(term), p_trunc=ptr(trunc),
+                                p_fin=ptr(fin), p_info=ptr(info_i), fn=self._lib.lib.salp_vec_step, h=self._lib._h,
+                                flags=self._flags, vp=ctypes.c_void_p)
+
+    def step(self, actions, want_final_observation: bool = True):
+        """One step of every env.  The returned tensors are the env's own output buffers: they are
+        overwritten by the next call (clone what must be kept).  `info["score"]` of the reference
+        (snake:196) is `info["food_collected"] * food_reward`."""
+        c = getattr(self, "_step_cache", None)
+        if c is None:
+            self._prepare_step()
+            c = self._step_cache
+        t = self._torch
+        if t is not None and isinstance(actions, t.Tensor) and actions.is_cuda and actions.dtype == t.float32 \
+                and actions.is_contiguous() and actions.numel() == self.num_envs * self.act_dim:
+            a = actions
+            p_act = c["vp"](a.data_ptr())
+            stream = c["vp"](t.cuda.current_stream(self.device).cuda_stream)
+        else:
+            a = self._actions_in(actions, (self.num_envs,))
+            p_act = self._lib._ptr(a)
+            stream = c["vp"](self._stream)
+        rc = c["fn"](c["h"], p_act, c["p_obs"], c["p_rew"], c["p_term"], c["p_trunc"],
+                     c["p_fin"] if want_final_observation else None, c["p_info"], c["flags"], stream)
+        if rc != 0:
+            _capi.check(self._lib.lib, rc, "salp_vec_step")
+        if want_final_observation:
+            if t is not None:
+                t.logical_or(c["term"], c["trunc"], out=c["done"])
+            else:
+                np.logical_or(c["term"], c["trunc"], out=c["done"])
+        return c["obs"], c["rew"], c["term"], c["trunc"], c["info"]
 
     def rollout(self, actions=None, horizon: Optional[int] = None, want_obs: bool = True,
                 want_final_observation: bool = False, out: Optional[dict] = None) -> dict:
@@ -186,6 +219,7 @@ class SalpVectorEnv:
     def close(self):
         self._lib.close()
         self._bufs.clear()
+        self._step_cache = None
 
     # ------------------------------------------------------------------ state access
     def get_state(self):
