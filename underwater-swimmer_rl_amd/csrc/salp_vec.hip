@@ -19,6 +19,7 @@
 
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "../../include/salp_vec.h"
 #include "salp_device.h"
@@ -57,8 +58,13 @@ struct IOPtrs {
 
 // FULL = the common rollout signature (act, obs, reward, terminated, truncated all present; no
 // final_obs / info): no per-step null tests.
-template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H) {
+// RAGGED = false: every wavefront of the launch is either full (64 envs) or empty, so no store is
+// predicated and the compiler can count the stores issued after the action prefetch (it then waits
+// for the prefetch alone instead of draining all stores with s_waitcnt vmcnt(0) every step).
+// RAGGED = true: the same loop with per-lane predicates; the host launches it for the last
+// n % 64 envs only (one wavefront).  `env_begin/env_end`: the env range of this launch.
+template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL, bool RAGGED>
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end) {
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
   constexpr int PITCH = 4 * QMAX + 4;     // LDS row pitch in floats (pad 16 B: conflict-free b128 writes)
   __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * kWave * PITCH];
@@ -66,17 +72,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid / kWave;
-#ifdef SALP_EXP_XCD_REMAP   // blocks are dealt round-robin over the 8 XCDs: give each XCD a contiguous env range
-  const unsigned nb = gridDim.x;
-  const unsigned bid = (nb % 8 == 0) ? ((blockIdx.x % 8) * (nb / 8) + blockIdx.x / 8) : blockIdx.x;
-#else
-  const unsigned bid = blockIdx.x;
-#endif
-  const int64_t env0 = (int64_t)bid * kBlock + (int64_t)wave * kWave;  // first env of this wavefront
+  const int64_t env0 = env_begin + (int64_t)blockIdx.x * kBlock + (int64_t)wave * kWave;  // first env of this wavefront
   const int64_t env = env0 + lane;
-  const bool active = env < P.n;
-  const int64_t envc = active ? env : (P.n - 1);
-  const int rows = (int)((P.n - env0) < kWave ? ((P.n - env0) > 0 ? (P.n - env0) : 0) : kWave);
+  const int rows = (int)((env_end - env0) < kWave ? ((env_end - env0) > 0 ? (env_end - env0) : 0) : kWave);
+  const bool active = RAGGED ? (env < env_end) : true;     // !RAGGED: rows is 64 or 0
+  const int64_t envc = (env < env_end) ? env : (env_end - 1);
   const uint64_t genv = P.env_base + (uint64_t)envc;
   const int K = (KMAX == 3) ? 3 : P.K;
   const int Q = 3 + K;
@@ -87,33 +87,42 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
 
   // Tile flush plan, fixed for the whole launch: float4 number f = j*64 + lane of the wavefront's
   // [rows x Q] tile lives at LDS row f / Q, column f % Q and goes to global float4 f of the run.
-  int lds_off[QMAX];      // float offset inside the tile, or -1 when this lane has nothing to move
+  int lds_off[QMAX];      // float offset inside the tile (-1: nothing to move, RAGGED only)
 #pragma unroll
   for (int j = 0; j < QMAX; ++j) {
     const int f = j * kWave + lane;
     const int r = f / Q;
-    lds_off[j] = (j < Q && f < rows * Q) ? (r * PITCH + 4 * (f - r * Q)) : -1;
+    lds_off[j] = (!RAGGED || f < rows * Q) ? (r * PITCH + 4 * (f - r * Q)) : -1;
   }
+
+  // Event statistics (episodes, terminations, food, ...) change on rare steps only: they are
+  // accumulated with LDS integer atomics inside the rare-event branch instead of living in VGPRs.
+  __shared__ unsigned long long blk_stats[16];
+  if (tid < 16) blk_stats[tid] = 0ull;
+  __syncthreads();
 
   Env<FMAX> e;
   load_env(e, S, P, envc);
 
-  // per-lane statistics
-  double st_reward = 0.0, st_epret = 0.0;
-  int st_eps = 0, st_term = 0, st_trunc = 0, st_coll = 0, st_food = 0, st_eplen = 0;
+  double st_reward = 0.0;   // the one per-step statistic
 
-#ifdef SALP_EXP_STAGGER   // experiment: offset the four wavefronts of a SIMD by a quarter step each
-  for (int k = 0; k < (int)((blockIdx.x >> SALP_EXP_STAGGER_SHIFT) & 3) * SALP_EXP_STAGGER; ++k) __builtin_amdgcn_s_sleep(24);
-#endif
   float a0 = io.act[envc * AD];
   float a1 = FORCED ? 0.f : io.act[envc * AD + 1];
+  // Everything loaded so far is complete before the loop is entered: otherwise the waitcnt pass keeps
+  // a conservative `s_waitcnt vmcnt(1)` on the first use of the action inside the loop (for the entry
+  // path), and that wait drains the previous step's stores on every iteration.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
+  const int Hrun = (rows > 0) ? H : 0;   // a wavefront past the end of the range runs zero steps
+#ifdef SALP_EXP_BLOCK_SYNC
+  const bool block_full = env_begin + ((int64_t)blockIdx.x + 1) * kBlock <= env_end;
+#endif
 #pragma unroll 1
-  for (int t = 0; t < H; ++t) {
+  for (int t = 0; t < Hrun; ++t) {
     const int64_t rowbase = (int64_t)t * P.n;
     const float c0 = a0, c1 = a1;
-    if (t + 1 < H) {  // prefetch the next step's action
-      const int64_t nb = (rowbase + P.n + envc) * AD;
+    {  // prefetch the next step's action (the last step re-reads its own: keeps the load unconditional)
+      const int64_t nb = (rowbase + ((t + 1 < H) ? P.n : 0) + envc) * AD;
       a0 = io.act[nb];
       if (!FORCED) a1 = io.act[nb + 1];
     }
@@ -131,16 +140,14 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
 #ifdef SALP_EXP_NO_SMALL_STORES
     if (rows < 0)
 #endif
-    {
+    if (active) {
       // reward: one dword per lane (256 B per wavefront); flags: one byte per lane.  (Rebuilding the
       // 64 flag bytes from a ballot and storing 16 dwords was measured: no faster in the memory
       // pipeline and slower overall, profiles/r01/ab_notes.md.)
-      if (active && (FULL || io.reward)) io.reward[rowbase + env] = o.reward;
-      if (active) {
-        if (FULL || io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
-        if (FULL || io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
-      }
-      if (active && !FULL && io.info) {
+      if (FULL || io.reward) io.reward[rowbase + env] = o.reward;
+      if (FULL || io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
+      if (FULL || io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
+      if (!FULL && io.info) {
         int32_t* ip = io.info + (rowbase + env) * SALP_INFO_COLS;
         ip[SALP_INFO_FOOD_COLLECTED] = e.fc;
         ip[SALP_INFO_STEPS_SINCE_FOOD] = e.ssf;
@@ -148,18 +155,24 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
       }
     }
     st_reward += (double)o.reward;
-    st_food += o.collected ? 1 : 0;
-    st_coll += o.collision ? 1 : 0;
 
     // rare events: respawn of a collected food (snake:179-180), then same-step autoreset
     int todo = (o.collected && P.respawn) ? 1 : 0;
-    if (__any(todo > 0 || done)) {
+    if (__any(o.collected || done)) {
       int limit = 50;
+      if (active && io.stats) {
+        if (o.collected) atomicAdd(&blk_stats[ST_FOOD], 1ull);
+        if (o.collision) atomicAdd(&blk_stats[ST_COLL], 1ull);
+        if (done) {
+          atomicAdd(&blk_stats[ST_EPISODES], 1ull);
+          atomicAdd(&blk_stats[o.terminated ? ST_TERM : ST_TRUNC], 1ull);
+          atomicAdd(&blk_stats[ST_EPLEN], (unsigned long long)e.eplen);
+          atomicAdd(&blk_stats[ST_EPRET], (unsigned long long)__double2ll_rn(e.epret * SALP_FIXED_SCALE));
+        }
+      }
 #pragma unroll 1
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1 && done) {
-          st_eps += 1; st_term += o.terminated ? 1 : 0; st_trunc += o.truncated ? 1 : 0;
-          st_eplen += e.eplen; st_epret += e.epret;
           if (!FULL && io.final_obs && active) {
             float fo[12 + 4 * KMAX];
             observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, fo);
@@ -196,47 +209,53 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      float4* gout = reinterpret_cast<float4*>(io.obs + (rowbase + env0) * OD) + lane;
+      v4f* gout = reinterpret_cast<v4f*>(io.obs + (rowbase + env0) * OD) + lane;
 #ifdef SALP_EXP_NO_OBS_STORE    // experiment build: everything but the observation stream
       if (rows < 0)
 #endif
+      {
+        // write-once stream far larger than L2 / Infinity Cache: non-temporal stores (measured -2.4 %)
+        v4f tv[QMAX];
 #pragma unroll
-      for (int j = 0; j < QMAX; ++j) {
-#ifdef SALP_EXP_PLAIN_STORE
-        if (lds_off[j] >= 0) gout[j * kWave] = *reinterpret_cast<const float4*>(tile + lds_off[j]);
-#else   // write-once stream far larger than L2 / Infinity Cache: non-temporal (measured -2.4 %)
-        if (lds_off[j] >= 0) __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(tile + lds_off[j]), reinterpret_cast<v4f*>(&gout[j * kWave]));
-#endif
+        for (int j = 0; j < QMAX; ++j)
+          if (j < Q && (!RAGGED || lds_off[j] >= 0)) tv[j] = *reinterpret_cast<const v4f*>(tile + lds_off[j]);
+#pragma unroll
+        for (int j = 0; j < QMAX; ++j)
+          if (j < Q && (!RAGGED || lds_off[j] >= 0)) __builtin_nontemporal_store(tv[j], &gout[j * kWave]);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#ifdef SALP_EXP_VMCNT
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SALP_EXP_VMCNT) : "memory");
+#elif !defined(SALP_EXP_NO_DRAIN)
+    // Drain this step's stores before the next step.  Measured (profiles/r01/ab_notes.md): letting
+    // stores run ahead (vmcnt(9)) is 2-6 % SLOWER than draining — wavefronts that stay in step keep
+    // the write stream of all CUs inside one contiguous [N x 96 B] slab at a time.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#endif
+#ifdef SALP_EXP_BLOCK_SYNC
+    if (block_full) __syncthreads();
+#endif
   }
 
-  if (active) store_env(e, S, P, env);
+  if (rows > 0 && active) store_env(e, S, P, env);
 
   if (io.stats) {
-    // wavefront shuffles -> LDS across the 4 wavefronts -> one atomic per block and statistic
-    __shared__ long long red[kBlock / kWave][10];
-    if (!active) { st_reward = 0.0; st_epret = 0.0; st_eps = st_term = st_trunc = st_coll = st_food = st_eplen = 0; }
-    const double wr = wave_sum(st_reward), we = wave_sum(st_epret);
-    const int weps = wave_sum(st_eps), wterm = wave_sum(st_term), wtrunc = wave_sum(st_trunc);
-    const int wcoll = wave_sum(st_coll), wfood = wave_sum(st_food), weplen = wave_sum(st_eplen);
-    const int wact = wave_sum(active ? 1 : 0);
+    // reward sum: wavefront shuffles, then one LDS atomic per wavefront; env-step count likewise.
+    // Then one 64-bit integer global atomic per block and statistic into one of 64 replicas.
+    if (!active || rows == 0) st_reward = 0.0;
+    const double wr = wave_sum(st_reward);
+    const int wact = wave_sum((active && rows > 0) ? 1 : 0);
     if (lane == 0) {
-      red[wave][ST_STEPS] = (long long)wact * H;
-      red[wave][ST_EPISODES] = weps; red[wave][ST_TERM] = wterm; red[wave][ST_TRUNC] = wtrunc;
-      red[wave][ST_COLL] = wcoll; red[wave][ST_FOOD] = wfood; red[wave][ST_EPLEN] = weplen;
-      red[wave][ST_REWARD] = __double2ll_rn(wr * SALP_FIXED_SCALE);
-      red[wave][ST_EPRET] = __double2ll_rn(we * SALP_FIXED_SCALE);
+      atomicAdd(&blk_stats[ST_REWARD], (unsigned long long)__double2ll_rn(wr * SALP_FIXED_SCALE));
+      atomicAdd(&blk_stats[ST_STEPS], (unsigned long long)((long long)wact * H));
     }
     __syncthreads();
     if (tid <= ST_EPRET) {
-      long long v = 0;
-#pragma unroll
-      for (int w = 0; w < kBlock / kWave; ++w) v += red[w][tid];
-      if (v != 0) atomicAdd(&io.stats[blockIdx.x % SALP_STATS_REPLICAS].v[tid], (unsigned long long)v);
+      const unsigned long long v = blk_stats[tid];
+      if (v != 0) atomicAdd(&io.stats[blockIdx.x % SALP_STATS_REPLICAS].v[tid], v);
     }
   }
 }
@@ -437,28 +456,29 @@ int validate(const salp_config_t* c) {
   return SALP_OK;
 }
 
-typedef void (*rollout_fn)(DevParams, DevState, IOPtrs, int);
+typedef void (*rollout_fn)(DevParams, DevState, IOPtrs, int, int64_t, int64_t);
 typedef void (*reset_fn)(DevParams, DevState, const uint8_t*, float*, int);
 
-template <int FMAX, int KMAX, bool STD>
+template <int FMAX, int KMAX, bool STD, bool RAGGED>
 rollout_fn pick_rollout(bool forced, bool full) {
-  if (forced) return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, true>
-                          : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, false>;
-  return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, true>
-              : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, false>;
+  if (forced) return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, true, RAGGED>
+                          : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, false, RAGGED>;
+  return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, true, RAGGED>
+              : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, false, RAGGED>;
 }
 
 // Literal-constant kernels exist for the reference's constants with K = 3 (every preset); any
 // other configuration runs the generic instantiation (runtime constants, F <= 16, K <= 8).
+template <bool RAGGED>
 rollout_fn rollout_kernel_for(const salp_vec* h, bool full) {
   const bool forced = h->P.forced != 0;
   if (h->kmax == 3 && h->std_consts) {
-    if (h->fmax == 1) return pick_rollout<1, 3, true>(forced, full);
-    if (h->fmax == 4) return pick_rollout<4, 3, true>(forced, full);
-    return pick_rollout<16, 3, true>(forced, full);
+    if (h->fmax == 1) return pick_rollout<1, 3, true, RAGGED>(forced, full);
+    if (h->fmax == 4) return pick_rollout<4, 3, true, RAGGED>(forced, full);
+    return pick_rollout<16, 3, true, RAGGED>(forced, full);
   }
-  return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, false>
-                : (rollout_fn)salp_rollout_kernel<16, 8, false, false, false>;
+  return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, false, RAGGED>
+                : (rollout_fn)salp_rollout_kernel<16, 8, false, false, false, RAGGED>;
 }
 reset_fn reset_kernel_for(const salp_vec* h) {
   if (h->kmax == 3 && h->std_consts) {
@@ -506,11 +526,19 @@ struct Bump {  // carve sub-buffers out of the staging allocation
 };
 
 int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
-  const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
   const bool full = io.obs && io.reward && io.terminated && io.truncated && !io.final_obs && !io.info;
-  rollout_fn fn = rollout_kernel_for(h, full);
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H);
-  HIP_TRY(hipGetLastError());
+  const int64_t n_full = h->n / kWave * kWave;      // envs in full wavefronts: unpredicated kernel
+  if (n_full > 0) {
+    const unsigned grid = (unsigned)((n_full + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(rollout_kernel_for<false>(h, full), dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
+                       (int64_t)0, n_full);
+    HIP_TRY(hipGetLastError());
+  }
+  if (n_full < h->n) {                              // the last n % 64 envs: one predicated wavefront
+    hipLaunchKernelGGL(rollout_kernel_for<true>(h, full), dim3(1), dim3(kBlock), 0, st, h->P, h->S, io, H,
+                       n_full, h->n);
+    HIP_TRY(hipGetLastError());
+  }
   return SALP_OK;
 }
 
