@@ -40,9 +40,12 @@
  *                                                x = lo+(hi-lo)*u53(w0,w1), y likewise from (w2,w3)
  *     random food count (snake:146)              1 + ((w0 * n) >> 32)
  *   u53(a,b) = ((a>>5)*2^26 + (b>>6)) / 2^53.
- *   Device-generated actions (salp_vec_rollout with act == NULL) use
- *     Philox4x32-10(counter = (env_lo, env_hi, t, 1 + j), key) -> a_j = (w0>>8)*2^-23 - 1
- *   with t = the handle's global step count and j the action component.
+ *   Device-generated actions (salp_vec_rollout with act == NULL): with t = the handle's global step
+ *   count and j the action component,
+ *     w = word (t & 3) of Philox4x32-10(counter = (env_lo, env_hi, t >> 2, 1 + j), key)
+ *     a_j = (w >> 8) * 2^-23 - 1   in [-1, 1)      (nozzle direction)
+ *     a_0 = (w >> 8) * 2^-24       in [0, 1)       (inhale control, 2-action mode only)
+ *   (one block serves four consecutive steps of a component).
  */
 #ifndef SALP_VEC_H
 #define SALP_VEC_H

@@ -479,12 +479,14 @@ int salp_oracle_observe(salp_oracle_t* h, float* obs) {
 
 static float device_action(const salp_oracle_t* h, int64_t i, int64_t t, int j, int act_dim) {
   uint64_t g = (uint64_t)(h->base + i);
-  uint32_t ctr[4] = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)t, (uint32_t)(1 + j)};
+  uint32_t ts = (uint32_t)t;   /* word ts & 3 of block ts >> 2 of the action stream 1 + j */
+  uint32_t ctr[4] = {(uint32_t)g, (uint32_t)(g >> 32), ts >> 2, (uint32_t)(1 + j)};
   uint32_t key[2] = {(uint32_t)h->seed, (uint32_t)(h->seed >> 32)};
   uint32_t w[4];
   salp_oracle_philox4x32_10(ctr, key, w);
-  if (act_dim == 2 && j == 0) return (float)(w[0] >> 8) * 5.9604644775390625e-8f; /* [0,1) */
-  return (float)(w[0] >> 8) * 1.1920928955078125e-7f - 1.0f;                      /* [-1,1) */
+  uint32_t x = w[ts & 3u];
+  if (act_dim == 2 && j == 0) return (float)(x >> 8) * 5.9604644775390625e-8f; /* [0,1) */
+  return (float)(x >> 8) * 1.1920928955078125e-7f - 1.0f;                      /* [-1,1) */
 }
 
 static int rollout_impl(salp_oracle_t* h, const float* act, const double* act64, int32_t horizon, float* obs,

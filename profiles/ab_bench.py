@@ -21,6 +21,8 @@ def main():
         elif a == "--preset": preset = next(it)
         else:
             k, v = a.split("=", 1); variants.append((k, os.path.abspath(v)))
+    # a variant name ending in "+gen" runs the device-generated-action mode (act = NULL, actions
+    # written to act_out); "+gennoout" the same without act_out
     cfg = pkg.load_env_config(preset)
     dev = torch.device("cuda", 0)
     act = torch.rand((H, n, cfg.act_dim), device=dev) * 2 - 1
@@ -37,8 +39,10 @@ def main():
     def launch(name):
         lib, h, _ = handles[name]
         vp = ctypes.c_void_p
-        _capi.check(lib, lib.salp_vec_rollout(h, vp(act.data_ptr()), H, vp(obs.data_ptr()), vp(rew.data_ptr()),
-                    vp(term.data_ptr()), vp(trunc.data_ptr()), None, None, 1, vp(torch.cuda.current_stream().cuda_stream)), "rollout")
+        a_in = None if "+gen" in name else vp(act.data_ptr())
+        a_out = vp(act.data_ptr()) if name.endswith("+gen") else None
+        _capi.check(lib, lib.salp_vec_rollout(h, a_in, H, vp(obs.data_ptr()), vp(rew.data_ptr()),
+                    vp(term.data_ptr()), vp(trunc.data_ptr()), None, a_out, 1, vp(torch.cuda.current_stream().cuda_stream)), "rollout")
     times = {name: [] for name, _ in variants}
     warm = int(os.environ.get("AB_WARM", "8"))   # advance every variant to the same (desynchronised) phase mix
     for name, _ in variants:

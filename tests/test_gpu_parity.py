@@ -195,14 +195,17 @@ def test_reset_observation_and_mask():
     dev.close()
 
 
-def test_device_generated_actions_match_oracle_stream():
-    cfg = pkg.load_env_config("single_food")
-    n, H, seed = 640, 200, 99
+@pytest.mark.parametrize("n,preset,over", [(640, "single_food", {}), (700, "sac_gail", {}),
+                                            (333, "single_food", dict(forced_breathing=False))])
+def test_device_generated_actions_match_oracle_stream(n, preset, over):
+    """act == NULL: in-kernel generation (FULL signature), full and ragged wavefronts, 1 and 2 actions."""
+    cfg = pkg.load_env_config(preset, **over)
+    H, seed = 203, 99
     got, dev = run_device(cfg, n, None, horizon=H, seed=seed)
     orc = ol.OracleVec(cfg, n, seed=seed)
     ref = orc.rollout(None, horizon=H)
     assert np.array_equal(got["actions"], ref["actions"])
-    assert got["actions"].min() >= -1.0 and got["actions"].max() < 1.0
+    assert got["actions"][..., -1].min() >= -1.0 and got["actions"][..., -1].max() < 1.0
     assert_parity(cfg, got, ref, "device actions")
     # second launch continues the action stream at global step H
     got2, _ = run_device(cfg, n, None, horizon=50, dev=dev)

@@ -63,7 +63,10 @@ struct IOPtrs {
 // for the prefetch alone instead of draining all stores with s_waitcnt vmcnt(0) every step).
 // RAGGED = true: the same loop with per-lane predicates; the host launches it for the last
 // n % 64 envs only (one wavefront).  `env_begin/env_end`: the env range of this launch.
-template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL, bool RAGGED>
+// GEN = actions are generated in the kernel (salp_vec_rollout with act == NULL): no read stream at
+// all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
+// profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
+template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL, bool RAGGED, bool GEN>
 __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end) {
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
   constexpr int PITCH = 4 * QMAX + 4;     // LDS row pitch in floats (pad 16 B: conflict-free b128 writes)
@@ -106,8 +109,12 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
 
   double st_reward = 0.0;   // the one per-step statistic
 
-  float a0 = io.act[envc * AD];
-  float a1 = FORCED ? 0.f : io.act[envc * AD + 1];
+  float a0 = 0.f, a1 = 0.f;
+  U4 aw0 = {0u, 0u, 0u, 0u}, aw1 = {0u, 0u, 0u, 0u};   // GEN: the current Philox block of each action component
+  if (!GEN) {
+    a0 = io.act[envc * AD];
+    a1 = FORCED ? 0.f : io.act[envc * AD + 1];
+  }
   // Everything loaded so far is complete before the loop is entered: otherwise the waitcnt pass keeps
   // a conservative `s_waitcnt vmcnt(1)` on the first use of the action inside the loop (for the entry
   // path), and that wait drains the previous step's stores on every iteration.
@@ -120,8 +127,28 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
 #pragma unroll 1
   for (int t = 0; t < Hrun; ++t) {
     const int64_t rowbase = (int64_t)t * P.n;
-    const float c0 = a0, c1 = a1;
-    {  // prefetch the next step's action (the last step re-reads its own: keeps the load unconditional)
+    float c0 = a0, c1 = a1;
+    if (GEN) {
+      // device action stream (include/salp_vec.h "Randomness"): word ts & 3 of block ts >> 2
+      const uint32_t ts = (uint32_t)(io.global_step + t);
+      if (t == 0 || (ts & 3u) == 0u) {   // wave-uniform
+        aw0 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 1u, P.seed_lo, P.seed_hi);
+        if (!FORCED) aw1 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 2u, P.seed_lo, P.seed_hi);
+      }
+      const uint32_t k = ts & 3u;
+      const uint32_t w0 = (k == 0) ? aw0.x : (k == 1) ? aw0.y : (k == 2) ? aw0.z : aw0.w;
+      if (FORCED) {
+        c0 = (float)(w0 >> 8) * 1.1920928955078125e-7f - 1.0f;              // [-1, 1)
+      } else {
+        const uint32_t w1 = (k == 0) ? aw1.x : (k == 1) ? aw1.y : (k == 2) ? aw1.z : aw1.w;
+        c0 = (float)(w0 >> 8) * 5.9604644775390625e-8f;                     // inhale control in [0, 1)
+        c1 = (float)(w1 >> 8) * 1.1920928955078125e-7f - 1.0f;
+      }
+      if (io.act_out && active) {
+        io.act_out[(rowbase + env) * AD] = c0;
+        if (!FORCED) io.act_out[(rowbase + env) * AD + 1] = c1;
+      }
+    } else {  // prefetch the next step's action (the last step re-reads its own: keeps the load unconditional)
       const int64_t nb = (rowbase + ((t + 1 < H) ? P.n : 0) + envc) * AD;
       a0 = io.act[nb];
       if (!FORCED) a1 = io.act[nb + 1];
@@ -266,16 +293,22 @@ __global__ __launch_bounds__(kBlock) void salp_gen_actions_kernel(DevParams P, f
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= P.n) return;
   const uint64_t genv = P.env_base + (uint64_t)i;
+  U4 w = {0u, 0u, 0u, 0u}, w2 = {0u, 0u, 0u, 0u};
   for (int t = 0; t < H; ++t) {
     const uint32_t ts = (uint32_t)(global_step + t);
-    const U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts, 1u, P.seed_lo, P.seed_hi);
+    if (t == 0 || (ts & 3u) == 0u) {
+      w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 1u, P.seed_lo, P.seed_hi);
+      if (AD == 2) w2 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 2u, P.seed_lo, P.seed_hi);
+    }
+    const uint32_t k = ts & 3u;
+    const uint32_t x0 = (k == 0) ? w.x : (k == 1) ? w.y : (k == 2) ? w.z : w.w;
+    const uint32_t x1 = (k == 0) ? w2.x : (k == 1) ? w2.y : (k == 2) ? w2.z : w2.w;
     const int64_t o = ((int64_t)t * P.n + i) * AD;
     if (AD == 1) {
-      act[o] = (float)(w.x >> 8) * 1.1920928955078125e-7f - 1.0f;
+      act[o] = (float)(x0 >> 8) * 1.1920928955078125e-7f - 1.0f;
     } else {
-      act[o] = (float)(w.x >> 8) * 5.9604644775390625e-8f;
-      const U4 w2 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts, 2u, P.seed_lo, P.seed_hi);
-      act[o + 1] = (float)(w2.x >> 8) * 1.1920928955078125e-7f - 1.0f;
+      act[o] = (float)(x0 >> 8) * 5.9604644775390625e-8f;
+      act[o + 1] = (float)(x1 >> 8) * 1.1920928955078125e-7f - 1.0f;
     }
   }
 }
@@ -460,25 +493,31 @@ typedef void (*rollout_fn)(DevParams, DevState, IOPtrs, int, int64_t, int64_t);
 typedef void (*reset_fn)(DevParams, DevState, const uint8_t*, float*, int);
 
 template <int FMAX, int KMAX, bool STD, bool RAGGED>
-rollout_fn pick_rollout(bool forced, bool full) {
-  if (forced) return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, true, RAGGED>
-                          : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, false, RAGGED>;
-  return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, true, RAGGED>
-              : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, false, RAGGED>;
+rollout_fn pick_rollout(bool forced, bool full, bool gen) {
+  if (full && gen)   // in-kernel action generation exists for the FULL output signature
+    return forced ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, true, RAGGED, true>
+                  : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, true, RAGGED, true>;
+  if (forced) return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, true, RAGGED, false>
+                          : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, false, RAGGED, false>;
+  return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, true, RAGGED, false>
+              : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, false, RAGGED, false>;
 }
 
 // Literal-constant kernels exist for the reference's constants with K = 3 (every preset); any
 // other configuration runs the generic instantiation (runtime constants, F <= 16, K <= 8).
+// True when in-kernel action generation is available for this handle and output signature.
+bool can_generate_in_kernel(const salp_vec* h, bool full) { return full && h->kmax == 3 && h->std_consts; }
+
 template <bool RAGGED>
-rollout_fn rollout_kernel_for(const salp_vec* h, bool full) {
+rollout_fn rollout_kernel_for(const salp_vec* h, bool full, bool gen) {
   const bool forced = h->P.forced != 0;
   if (h->kmax == 3 && h->std_consts) {
-    if (h->fmax == 1) return pick_rollout<1, 3, true, RAGGED>(forced, full);
-    if (h->fmax == 4) return pick_rollout<4, 3, true, RAGGED>(forced, full);
-    return pick_rollout<16, 3, true, RAGGED>(forced, full);
+    if (h->fmax == 1) return pick_rollout<1, 3, true, RAGGED>(forced, full, gen);
+    if (h->fmax == 4) return pick_rollout<4, 3, true, RAGGED>(forced, full, gen);
+    return pick_rollout<16, 3, true, RAGGED>(forced, full, gen);
   }
-  return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, false, RAGGED>
-                : (rollout_fn)salp_rollout_kernel<16, 8, false, false, false, RAGGED>;
+  return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, false, RAGGED, false>
+                : (rollout_fn)salp_rollout_kernel<16, 8, false, false, false, RAGGED, false>;
 }
 reset_fn reset_kernel_for(const salp_vec* h) {
   if (h->kmax == 3 && h->std_consts) {
@@ -527,15 +566,16 @@ struct Bump {  // carve sub-buffers out of the staging allocation
 
 int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
   const bool full = io.obs && io.reward && io.terminated && io.truncated && !io.final_obs && !io.info;
+  const bool gen = io.act == nullptr;               // only reached when can_generate_in_kernel()
   const int64_t n_full = h->n / kWave * kWave;      // envs in full wavefronts: unpredicated kernel
   if (n_full > 0) {
     const unsigned grid = (unsigned)((n_full + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(rollout_kernel_for<false>(h, full), dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
+    hipLaunchKernelGGL(rollout_kernel_for<false>(h, full, gen), dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
                        (int64_t)0, n_full);
     HIP_TRY(hipGetLastError());
   }
   if (n_full < h->n) {                              // the last n % 64 envs: one predicated wavefront
-    hipLaunchKernelGGL(rollout_kernel_for<true>(h, full), dim3(1), dim3(kBlock), 0, st, h->P, h->S, io, H,
+    hipLaunchKernelGGL(rollout_kernel_for<true>(h, full, gen), dim3(1), dim3(kBlock), 0, st, h->P, h->S, io, H,
                        n_full, h->n);
     HIP_TRY(hipGetLastError());
   }
@@ -706,7 +746,8 @@ static int rollout_impl(salp_vec_t* h, const float* act, int32_t H, float* obs, 
   if (flags & SALP_DEVICE_PTRS) {
     io.act = act; io.obs = obs; io.reward = reward; io.terminated = terminated; io.truncated = truncated;
     io.final_obs = final_obs; io.info = info; io.act_out = act_out;
-    if (!act) {  // device-generated actions: into act_out when given, else into the handle's buffer
+    const bool full_sig = obs && reward && terminated && truncated && !final_obs && !info;
+    if (!act && !can_generate_in_kernel(h, full_sig)) {  // generate into act_out when given, else into the handle's buffer
       float* dst = act_out;
       if (!dst) {
         const size_t need_a = HN * h->act_dim * sizeof(float);
