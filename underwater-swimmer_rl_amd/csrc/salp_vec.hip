@@ -514,6 +514,7 @@ rollout_fn rollout_kernel_for(const salp_vec* h, bool full, bool gen) {
   if (h->kmax == 3 && h->std_consts) {
     if (h->fmax == 1) return pick_rollout<1, 3, true, RAGGED>(forced, full, gen);
     if (h->fmax == 4) return pick_rollout<4, 3, true, RAGGED>(forced, full, gen);
+    if (h->fmax == 12) return pick_rollout<12, 3, true, RAGGED>(forced, full, gen);
     return pick_rollout<16, 3, true, RAGGED>(forced, full, gen);
   }
   return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, false, RAGGED, false>
@@ -523,6 +524,7 @@ reset_fn reset_kernel_for(const salp_vec* h) {
   if (h->kmax == 3 && h->std_consts) {
     if (h->fmax == 1) return (reset_fn)salp_reset_kernel<1, 3, true>;
     if (h->fmax == 4) return (reset_fn)salp_reset_kernel<4, 3, true>;
+    if (h->fmax == 12) return (reset_fn)salp_reset_kernel<12, 3, true>;
     return (reset_fn)salp_reset_kernel<16, 3, true>;
   }
   return (reset_fn)salp_reset_kernel<16, 8, false>;
@@ -631,7 +633,8 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
   h->F = cfg->num_food_items; h->K = cfg->max_observed_food;
   h->obs_dim = 10 + 4 * h->K + 2; h->act_dim = cfg->forced_breathing ? 1 : 2;
   h->kmax = (h->K == 3) ? 3 : 8;
-  h->fmax = (h->kmax == 3) ? (h->F <= 1 ? 1 : (h->F <= 4 ? 4 : 16)) : 16;
+  // food slots held in registers: 1 (single_food*.yaml), 4, 12 (defaults.yaml / sac_gail.yaml), 16
+  h->fmax = (h->kmax == 3) ? (h->F <= 1 ? 1 : (h->F <= 4 ? 4 : (h->F <= 12 ? 12 : 16))) : 16;
   const int64_t pitch = (int64_t)align_up((size_t)n_envs, 64);
   h->P = make_params(*cfg, n_envs, pitch, seed, env_index_base);
   h->std_consts = is_std(h->P) ? 1 : 0;
