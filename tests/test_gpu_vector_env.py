@@ -122,15 +122,14 @@ def test_step_is_graph_capturable():
         env.step(act, want_final_observation=False)
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
-    ref_obs = orc.reset()               # same reset on the oracle; replay the warm-up step there too
-    a0 = np.tanh(ref_obs @ w.cpu().numpy()).astype(np.float32)
+    orc.reset()                         # the oracle follows the same reset sequence
     env.reset()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         act.copy_(torch.tanh(env._bufs["obs"] @ w))
         env.step(act, want_final_observation=False)
     # the capture itself does not execute; state is still the reset state
-    ref = orc.reset()
+    orc.reset()
     for t in range(30):
         g.replay()
         torch.cuda.synchronize()
