@@ -64,7 +64,10 @@ def main():
         T = min(T_KEEP, len(act))
         base = np.concatenate([obs[:1, :10], nxt[:T, :10]]).astype(np.float32)
         a = np.asarray(act[:T], dtype=np.float64).reshape(T)     # recorded as fp64 (multiples of 0.03 etc.)
+        # `observations` / `act32`: the (obs[24], action) pairs the reference's GAIL path samples
+        # (training/expert_buffer.py:73-102), first T steps
         np.savez_compressed(os.path.join(HERE, f"human_demo_{i}.npz"), actions=a, base_obs=base,
+                            observations=np.ascontiguousarray(obs[:T]).astype(np.float32), act32=a.astype(np.float32).reshape(T, 1),
                             source=np.array(os.path.basename(f)), episode_length=np.array(len(act)))
         print(os.path.basename(f), "steps", len(act), "kept", T, "act dtype", act.dtype, "obs dtype", obs.dtype)
 

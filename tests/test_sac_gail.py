@@ -105,3 +105,20 @@ def test_sac_trains_on_the_hip_vector_env():
     d = disc.update(eb.sample(128), {"observations": env.observe().clone(), "actions": agent.act(env.observe())})
     assert math.isfinite(d["discriminator_loss"])
     env.close()
+
+
+def test_discriminator_on_the_reference_human_demos():
+    """GAIL on the reference's own recorded demonstrations (tests/golden/human_demo_*.npz: first 1500
+    (obs[24], action) pairs of each of data/expert_demos/human/*.pkl)."""
+    import os
+    torch.manual_seed(0)
+    d = Discriminator(24, 1, (64, 64), learning_rate=1e-3, device="cpu")
+    eb = ExpertBuffer(24, 1, device="cpu")
+    n = eb.load_directory(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"), "human_demo_*.npz")
+    assert n == 5 and len(eb) == 5 * 1500
+    b = eb.sample(256)
+    assert b["observations"].shape == (256, 24) and b["actions"].abs().max() <= 1.0
+    assert b["observations"][:, 6].min() >= 1.0            # body size column of real observations
+    for _ in range(200):       # "agent" = uniformly random observations / actions
+        m = d.update(eb.sample(128), {"observations": torch.rand(128, 24) * 2 - 1, "actions": torch.rand(128, 1) * 2 - 1})
+    assert m["discriminator_accuracy"] > 0.9

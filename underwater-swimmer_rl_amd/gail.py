@@ -79,8 +79,20 @@ class ExpertBuffer:
         self.episodes += 1
 
     def load_npz(self, path: str):
+        """`observations` [T, obs_dim] and `act32` or `actions` [T, action_dim] from a .npz demo."""
         z = np.load(path, allow_pickle=False)
-        self.add_episode(z["observations"], z["actions"])
+        act = z["act32"] if "act32" in z.files else z["actions"]
+        self.add_episode(z["observations"], act)
+
+    def load_directory(self, directory: str, pattern: str = "*.npz") -> int:
+        """expert_buffer.py:148-187 `load_directory`, for .npz demos.  Returns episodes loaded."""
+        import glob
+        import os
+        n = 0
+        for p in sorted(glob.glob(os.path.join(directory, pattern))):
+            self.load_npz(p)
+            n += 1
+        return n
 
     def sample(self, batch_size: int) -> Dict[str, torch.Tensor]:
         if len(self) == 0:
