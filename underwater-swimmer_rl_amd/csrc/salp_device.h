@@ -516,10 +516,17 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
   // legacy:316-352 _update_physics
   e.vx = e.vx * CV(drag); e.vy = e.vy * CV(drag); e.om = e.om * CV(ang_drag);
   e.x = e.x + e.vx; e.y = e.y + e.vy; e.th = e.th + e.om;
+  // legacy:329-332 `while theta > pi: theta -= 2 pi` / `while theta < -pi: ...`.  |omega| is far below
+  // 2 pi, so one conditional step each is the common case; the (bounded) loops only run if a lane
+  // is still outside, e.g. after an injected state.
+  if (e.th > SALP_PI) e.th -= SALP_2PI;
+  if (e.th < -SALP_PI) e.th += SALP_2PI;
+  if (__any(e.th > SALP_PI || e.th < -SALP_PI)) {
 #pragma unroll 1
-  for (int it = 0; it < 8 && e.th > SALP_PI; ++it) e.th -= SALP_2PI;
+    for (int it = 0; it < 8 && e.th > SALP_PI; ++it) e.th -= SALP_2PI;
 #pragma unroll 1
-  for (int it = 0; it < 8 && e.th < -SALP_PI; ++it) e.th += SALP_2PI;
+    for (int it = 0; it < 8 && e.th < -SALP_PI; ++it) e.th += SALP_2PI;
+  }
   {
     const double m = CV(margin) + r;
     const double hx = CV(W) - m, hy = CV(H) - m;

@@ -29,7 +29,10 @@ using namespace salp;
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kBlock = 256;
+#ifndef SALP_BLOCK
+#define SALP_BLOCK 256
+#endif
+constexpr int kBlock = SALP_BLOCK;
 constexpr int kWave = 64;
 
 __device__ __forceinline__ double wave_sum(double v) {
