@@ -56,6 +56,7 @@ enum {
 
 typedef struct salp_robot_vec salp_robot_vec_t;
 
+const char* salp_robot_last_error(void);   /* message of the calling thread's last failed salp_robot_* call */
 int salp_robot_config_default(salp_robot_config_t* cfg);
 int salp_robot_vec_create(const salp_robot_config_t* cfg, int64_t n_envs, int device_id, uint64_t seed,
                           int64_t env_index_base, salp_robot_vec_t** out);

@@ -53,6 +53,14 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = path or os.environ.get("SALP_HIP_LIBRARY", LIB_PATH)
+    # If PyTorch is installed, let it load ITS HIP runtime first: torch ships its own libamdhip64 and
+    # cannot initialise once the system copy (which this library would pull in) is already resident,
+    # whereas this library runs on either copy.
+    if os.environ.get("SALP_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.isfile(p):
         raise SalpError(
             f"HIP library not found at {p}; build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -7,9 +7,11 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "salp_vec.hip")
-DEPS = [SRC, os.path.join(HERE, "salp_device.h"),
-        os.path.join(HERE, "..", "..", "include", "salp_vec.h")]
+SRC = os.path.join(HERE, "salp_vec.hip")             # SalpSnakeEnv.step hot path
+SRC_ROBOT = os.path.join(HERE, "salp_robot.hip")     # HEAD Robot simulator
+DEPS = [SRC, SRC_ROBOT, os.path.join(HERE, "salp_device.h"),
+        os.path.join(HERE, "..", "..", "include", "salp_vec.h"),
+        os.path.join(HERE, "..", "..", "include", "salp_robot.h")]
 OUT = os.path.join(HERE, "libsalp_hip.so")
 # -ffp-contract=off: the fp64 state update must round exactly where the reference rounds
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -27,7 +29,7 @@ def build(force: bool = False, verbose: bool = False, out: str = OUT, defines=()
     """`out`/`defines` build experiment variants (profiles/ab_bench.py); the product is the default."""
     if not force and os.path.isfile(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
         return out
-    cmd = [hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out, SRC]
+    cmd = [hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out, SRC, SRC_ROBOT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=HERE)

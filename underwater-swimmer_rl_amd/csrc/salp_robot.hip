@@ -1,0 +1,510 @@
+// salp_robot.hip — batched HEAD simulator for gfx950 and the C ABI of
+// include/salp_robot.h: the reference's `Robot.step_through_cycle` (src/salp/environments/robot.py)
+// under `SalpRobotEnv.step/reset` (src/salp/environments/salp_robot_env.py), one robot per lane.
+//
+// One env step is one whole breathing cycle: up to ~1450 explicit-Euler steps of dt = 0.01 s, each a
+// rigid-body update with diagonal mass / inertia, quadratic + linear drag, a jet force during the
+// release phase, Euler-angle kinematics and a body->world rotation.  Unlike the SalpSnakeEnv kernel
+// this one has a real inner hot loop and almost no memory traffic (27 doubles of state in, 6 floats
+// out per cycle): it is bound by the fp64 VALU rate, not by HBM.
+//   * state lives in VGPRs for the whole cycle; lanes run different step counts (the cycle length is
+//     action-dependent), so the loop runs until the slowest lane of the wavefront is done;
+//   * the nozzle geometry (IK solve, three rotation matrices, jet direction, moment arm) is constant
+//     over a cycle and is evaluated once per env step;
+//   * the 3x3 matrices of the reference are diagonal (mass, inertia) or rotations about one axis, so
+//     they are written out as the handful of scalar products they are;
+//   * fp64 throughout, in the reference's operation order where that is defined (the reference's own
+//     3x3 products go through BLAS, so parity is a tolerance: tests/test_gpu_robot.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+
+#include <new>
+#include <string>
+
+#include "../../include/salp_robot.h"
+#include "salp_device.h"   // philox4x32_10, u53
+
+using namespace salp;
+
+namespace {
+
+constexpr int kRBlock = 256;
+constexpr double kPi = 3.141592653589793;
+
+struct RobotParams {
+  double dry_mass, init_length, init_width, max_contraction, density, dt, cd_min, cd_max;
+  double nz_l1, nz_l2, nz_area, nz_mass, nz_gamma;
+  double x_min, x_span, y_min, y_span;   // target placement, salp_robot_env.py:241-250
+  int max_cycles;
+  uint32_t seed_lo, seed_hi;
+  uint64_t env_base;
+  int64_t n, pitch;
+};
+
+struct RobotState {
+  double* f;    // [SALP_R_COUNT][pitch] (the public snapshot layout is also the device layout)
+};
+
+struct Rb {   // one robot in registers
+  double pos[3], vel[3], eul[3], om[3], vw[3], prevI[3];
+  double target[2], prev_dist, volume, angle1, angle2, time;
+  int cycle;
+  uint32_t rng;
+};
+
+__device__ __forceinline__ double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ double sq(double x) { return x * x; }
+
+__device__ __forceinline__ void load_robot(Rb& r, const RobotState& S, const RobotParams& P, int64_t i) {
+  const int64_t p = P.pitch;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    r.pos[k] = S.f[(SALP_R_POS + k) * p + i]; r.vel[k] = S.f[(SALP_R_VEL + k) * p + i];
+    r.eul[k] = S.f[(SALP_R_EULER + k) * p + i]; r.om[k] = S.f[(SALP_R_OMEGA + k) * p + i];
+    r.vw[k] = S.f[(SALP_R_VEL_WORLD + k) * p + i]; r.prevI[k] = S.f[(SALP_R_PREV_I + k) * p + i];
+  }
+  r.target[0] = S.f[SALP_R_TARGET * p + i]; r.target[1] = S.f[(SALP_R_TARGET + 1) * p + i];
+  r.prev_dist = S.f[SALP_R_PREV_DIST * p + i]; r.volume = S.f[SALP_R_VOLUME * p + i];
+  r.angle1 = S.f[SALP_R_ANGLE1 * p + i]; r.angle2 = S.f[SALP_R_ANGLE2 * p + i];
+  r.time = S.f[SALP_R_TIME * p + i];
+  r.cycle = (int)S.f[SALP_R_CYCLE * p + i]; r.rng = (uint32_t)S.f[SALP_R_RNG * p + i];
+}
+__device__ __forceinline__ void store_robot(const Rb& r, const RobotState& S, const RobotParams& P, int64_t i) {
+  const int64_t p = P.pitch;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    S.f[(SALP_R_POS + k) * p + i] = r.pos[k]; S.f[(SALP_R_VEL + k) * p + i] = r.vel[k];
+    S.f[(SALP_R_EULER + k) * p + i] = r.eul[k]; S.f[(SALP_R_OMEGA + k) * p + i] = r.om[k];
+    S.f[(SALP_R_VEL_WORLD + k) * p + i] = r.vw[k]; S.f[(SALP_R_PREV_I + k) * p + i] = r.prevI[k];
+  }
+  S.f[SALP_R_TARGET * p + i] = r.target[0]; S.f[(SALP_R_TARGET + 1) * p + i] = r.target[1];
+  S.f[SALP_R_PREV_DIST * p + i] = r.prev_dist; S.f[SALP_R_VOLUME * p + i] = r.volume;
+  S.f[SALP_R_ANGLE1 * p + i] = r.angle1; S.f[SALP_R_ANGLE2 * p + i] = r.angle2;
+  S.f[SALP_R_TIME * p + i] = r.time;
+  S.f[SALP_R_CYCLE * p + i] = (double)r.cycle; S.f[SALP_R_RNG * p + i] = (double)r.rng;
+}
+
+// robot.py:737-759 / 534-551 helpers on (length, width)
+__device__ __forceinline__ double water_volume(double length, double width) {
+  return 4.0 / 3 * kPi * (length / 2) * sq(width / 2);
+}
+__device__ __forceinline__ void inertia_diag(const RobotParams& P, double mass, double length, double width, double arm_norm2, double* I) {
+  const double In = P.nz_mass * arm_norm2;
+  const double hw2 = sq(width / 2), hl2 = sq(length / 2);
+  I[0] = 0.2 * mass * (hw2 + hw2);
+  I[1] = 0.2 * mass * (hl2 + hw2) + In;
+  I[2] = 0.2 * mass * (hw2 + hl2) + In;
+}
+__device__ __forceinline__ double drag_coefficient(const RobotParams& P, double length, double width) {  // robot.py:627-649
+  const double aspect = length / width;
+  const double init_aspect = P.init_length / P.init_width;
+  const double cl = P.init_length - P.max_contraction;
+  const double cw = P.init_length - cl + P.init_width;
+  const double min_aspect = cl / cw;
+  const double nr = clipd((aspect - min_aspect) / (init_aspect - min_aspect), 0.0, 1.0);
+  return P.cd_max - nr * (P.cd_max - P.cd_min);
+}
+// |r_nozzle + r_robot|: R_br @ (base + R_mb @ middle) = (-(l1 + l2), 0, 0) for any joint angles
+// (R_mb turns about z, the links lie on z; robot.py:132-151, 567-575)
+__device__ __forceinline__ double arm_x(const RobotParams& P, double length) { return -(P.nz_l1 + P.nz_l2) + -length / 2; }
+
+// robot.py:287-312 Robot.reset + salp_robot_env.py:98-128 (new target, prev_dist)
+__device__ __forceinline__ void reset_robot(Rb& r, const RobotParams& P, uint64_t genv) {
+  const U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), r.rng, 16u, P.seed_lo, P.seed_hi);
+  r.rng += 1u;
+  r.target[0] = P.x_min + P.x_span * u53(w.x, w.y);
+  r.target[1] = P.y_min + P.y_span * u53(w.z, w.w);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { r.pos[k] = 0.0; r.vel[k] = 0.0; r.eul[k] = 0.0; r.om[k] = 0.0; r.vw[k] = 0.0; }
+  r.time = 0.0; r.cycle = 0;
+  const double length = P.init_length, width = P.init_width;
+  r.volume = water_volume(length, width);
+  const double mass = P.dry_mass + P.density * r.volume + P.nz_mass;
+  inertia_diag(P, mass, length, width, sq(arm_x(P, length)), r.prevI);
+  const double dx = r.pos[0] - r.target[0], dy = r.pos[1] - r.target[1];
+  r.prev_dist = sqrt(dx * dx + dy * dy);
+}
+
+__device__ __forceinline__ void observe_robot(const Rb& r, float* o) {   // salp_robot_env.py:400-420
+  o[0] = (float)(r.pos[0] - r.target[0]); o[1] = (float)(r.pos[1] - r.target[1]);
+  o[2] = (float)r.vel[0]; o[3] = (float)r.vel[1]; o[4] = (float)r.eul[2]; o[5] = (float)r.om[2];
+}
+
+__global__ __launch_bounds__(kRBlock) void salp_robot_reset_kernel(RobotParams P, RobotState S, const uint8_t* mask, float* obs, int do_reset) {
+  const int64_t i = (int64_t)blockIdx.x * kRBlock + threadIdx.x;
+  if (i >= P.n) return;
+  Rb r;
+  load_robot(r, S, P, i);
+  if (do_reset && (!mask || mask[i])) {
+    reset_robot(r, P, P.env_base + (uint64_t)i);
+    store_robot(r, S, P, i);
+  }
+  if (obs) {
+    float o[6];
+    observe_robot(r, o);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) obs[i * 6 + k] = o[k];
+  }
+}
+
+// SalpRobotEnv.step (salp_robot_env.py:139-201): one breathing cycle per env.
+__global__ __launch_bounds__(kRBlock) void salp_robot_step_kernel(RobotParams P, RobotState S, const float* act, float* obs,
+                                                                  float* reward, uint8_t* terminated, uint8_t* truncated,
+                                                                  float* final_obs, int32_t* inner_steps) {
+  const int64_t i0 = (int64_t)blockIdx.x * kRBlock + threadIdx.x;
+  const bool active = i0 < P.n;
+  const int64_t i = active ? i0 : (P.n - 1);
+  const uint64_t genv = P.env_base + (uint64_t)i;
+  Rb r;
+  load_robot(r, S, P, i);
+
+  // _rescale_action (:129-137) in fp64
+  const double contraction = (double)act[i * 3 + 0] * 0.06;
+  const double coast_time = (double)act[i * 3 + 1] * 10.0;
+  const double yaw = (double)act[i * 3 + 2] * (kPi / 2);
+  // Nozzle.solve_angles (robot.py:55-85): target = R_br^T @ -(cos yaw, sin yaw, 0) = (-0, -sin yaw, cos yaw)
+  {
+    const double t1 = -sin(yaw), t2 = cos(yaw);
+    double a2 = acos(clipd(2 * t2 - 1, -1.0, 1.0));
+    if (a2 <= -kPi) a2 += 2 * kPi; else if (a2 > kPi) a2 -= 2 * kPi;
+    double a1 = 0.0;
+    if (a2 != 0.0) {
+      const double a = 0.5 * (cos(a2) - 1);
+      const double b = sqrt(2.0) * sin(a2) / 2;
+      a1 = asin(clipd(t1 / sqrt(a * a + b * b), -1.0, 1.0)) - atan2(b, a);
+    }
+    if (a1 <= -kPi) a1 += 2 * kPi; else if (a1 > kPi) a1 -= 2 * kPi;
+    r.angle1 = a1; r.angle2 = a2;
+  }
+  // Nozzle.get_nozzle_direction (robot.py:115-130): R_br @ R_mb @ R_nm @ (cos g, 0, sin g), constant over the cycle
+  double dir[3];
+  {
+    const double g = P.nz_gamma, cg = cos(g), sg = sin(g);
+    const double c2 = cos(r.angle2), s2 = sin(r.angle2), c1 = cos(r.angle1), s1 = sin(r.angle1);
+    // R_nm = R_theta_fixed @ R_nozzle(angle2); v1 = R_nm @ (cg, 0, sg)
+    const double nx = (cg * c2) * cg + (-sg) * sg;
+    const double ny = s2 * cg;
+    const double nzv = (sg * c2) * cg + cg * sg;
+    // R_mb = rotation about z by angle1
+    const double mx = c1 * nx + (-s1) * ny, my = s1 * nx + c1 * ny, mz = nzv;
+    // R_br = [[0,0,-1],[0,1,0],[1,0,0]]
+    dir[0] = -mz; dir[1] = my; dir[2] = mx;
+  }
+  // Robot.set_control (robot.py:335-358)
+  r.cycle += 1;
+  const double contract_rate = 0.06 / 3, release_rate = 0.06 / 1.5;
+  const double refill_time = contraction / contract_rate;
+  const double jet_time = contraction / release_rate;
+  const double total = refill_time + jet_time + coast_time;
+  double cycle_time = 0.0;
+  int steps = 0;
+  const double dt = P.dt;
+
+  // Robot.step_through_cycle (robot.py:422-445): lanes finish at different times
+#pragma unroll 1
+  while (__any(cycle_time < total)) {
+    if (cycle_time < total) {
+      // Robot.step (robot.py:387-396)
+      cycle_time += dt;
+      r.time += dt;
+      int state;   // update_state :360-373
+      if (cycle_time <= refill_time) state = 0;
+      else if (cycle_time <= refill_time + jet_time) state = 1;
+      else if (cycle_time <= refill_time + jet_time + coast_time) state = 2;
+      else state = 3;
+      // update_properties :375-385
+      const double prev_volume = r.volume;
+      const double prev_water_mass = prev_volume * P.density;
+      double length, width;
+      if (state == 0) { length = P.init_length - cycle_time * contract_rate; width = P.init_width + cycle_time * contract_rate; }
+      else if (state == 1) {
+        length = P.init_length - contraction + (cycle_time - refill_time) * release_rate;
+        width = P.init_width + contraction - (cycle_time - refill_time) * release_rate;
+      } else { length = P.init_length; width = P.init_width; }
+      const double area = kPi * (length / 2) * (width / 2);
+      r.volume = water_volume(length, width);
+      const double water_mass = P.density * r.volume;
+      const double mass = P.dry_mass + water_mass + P.nz_mass;
+      const double cd = drag_coefficient(P, length, width);
+      // _newton_equations :494-505
+      const double wxv0 = r.om[1] * r.vel[2] - r.om[2] * r.vel[1];
+      const double wxv1 = r.om[2] * r.vel[0] - r.om[0] * r.vel[2];
+      const double wxv2 = r.om[0] * r.vel[1] - r.om[1] * r.vel[0];
+      const double vnorm = sqrt(r.vel[0] * r.vel[0] + r.vel[1] * r.vel[1] + r.vel[2] * r.vel[2]);
+      const double kd = -0.5 * P.density * area * cd;
+      const double kq = kd * vnorm;
+      double jf[3] = {0.0, 0.0, 0.0};
+      if (state == 1) {
+        const double volume_rate = -(r.volume - prev_volume) / dt;
+        const double jet_speed = volume_rate / P.nz_area;
+        const double mass_rate = (water_mass - prev_water_mass) / dt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) jf[k] = 0.1 * mass_rate * (dir[k] * jet_speed);
+      }
+      const double inv_m = 1.0 / mass;
+      const double acc0 = inv_m * (jf[0] + (kq * r.vel[0] + kd * r.vel[0]) + mass * wxv0);
+      const double acc1 = inv_m * (jf[1] + (kq * r.vel[1] + kd * r.vel[1]) + mass * wxv1);
+      const double acc2 = inv_m * (jf[2] + (kq * r.vel[2] + kd * r.vel[2]) + mass * wxv2);
+      // _euler_equations :507-522
+      const double ax = arm_x(P, length);
+      double I[3];
+      inertia_diag(P, mass, length, width, ax * ax, I);
+      const double Iw0 = I[0] * r.om[0], Iw1 = I[1] * r.om[1], Iw2 = I[2] * r.om[2];
+      const double c0 = r.om[1] * Iw2 - r.om[2] * Iw1;
+      const double c1 = r.om[2] * Iw0 - r.om[0] * Iw2;
+      const double c2 = r.om[0] * Iw1 - r.om[1] * Iw0;
+      const double wnorm = sqrt(r.om[0] * r.om[0] + r.om[1] * r.om[1] + r.om[2] * r.om[2]);
+      const double kt = -P.density * cd * (width / 2) * sq(sq(length / 2)) * wnorm;
+      // jet torque = arm x jet_force, arm = (ax, 0, 0)
+      const double jt0 = 0.0, jt1 = -ax * jf[2], jt2 = ax * jf[1];
+      const double td0 = ((I[0] - r.prevI[0]) / dt) * r.om[0];
+      const double td1 = ((I[1] - r.prevI[1]) / dt) * r.om[1];
+      const double td2 = ((I[2] - r.prevI[2]) / dt) * r.om[2];
+      r.prevI[0] = I[0]; r.prevI[1] = I[1]; r.prevI[2] = I[2];
+      const double al0 = (1.0 / I[0]) * (jt0 + kt * r.om[0] + -c0 + 0.0 - td0);
+      const double al1 = (1.0 / I[1]) * (jt1 + kt * r.om[1] + -c1 + 0.0 - td1);
+      const double al2 = (1.0 / I[2]) * (jt2 + kt * r.om[2] + -c2 + 0.1 * vnorm - td2);
+      // _update_motion_states :524-532
+      r.vel[0] += acc0 * dt; r.vel[1] += acc1 * dt; r.vel[2] += acc2 * dt;
+      r.om[0] += al0 * dt; r.om[1] += al1 * dt; r.om[2] += al2 * dt;
+      {
+        double sp, cp, st, ct;
+        sincos(r.eul[0], &sp, &cp);
+        sincos(r.eul[1], &st, &ct);
+        const double tt = st / ct;
+        const double e0 = r.om[0] + (sp * tt) * r.om[1] + (cp * tt) * r.om[2];
+        const double e1 = cp * r.om[1] + (-sp) * r.om[2];
+        const double e2 = (sp / ct) * r.om[1] + (cp / ct) * r.om[2];
+        r.eul[0] += e0 * dt; r.eul[1] += e1 * dt; r.eul[2] += e2 * dt;
+      }
+      {
+        double sp, cp, st, ct, ss, cs;
+        sincos(r.eul[0], &sp, &cp);
+        sincos(r.eul[1], &st, &ct);
+        sincos(r.eul[2], &ss, &cs);
+        // R = R_z @ R_y @ R_x
+        const double r00 = cs * ct, r01 = cs * st * sp - ss * cp, r02 = cs * st * cp + ss * sp;
+        const double r10 = ss * ct, r11 = ss * st * sp + cs * cp, r12 = ss * st * cp - cs * sp;
+        const double r20 = -st, r21 = ct * sp, r22 = ct * cp;
+        r.vw[0] = r00 * r.vel[0] + r01 * r.vel[1] + r02 * r.vel[2];
+        r.vw[1] = r10 * r.vel[0] + r11 * r.vel[1] + r12 * r.vel[2];
+        r.vw[2] = r20 * r.vel[0] + r21 * r.vel[1] + r22 * r.vel[2];
+      }
+      r.pos[0] += r.vw[0] * dt; r.pos[1] += r.vw[1] * dt; r.pos[2] += r.vw[2] * dt;
+      ++steps;
+    }
+  }
+
+  // _calculate_reward (:203-243) and termination (:171-185)
+  const double dx = r.pos[0] - r.target[0], dy = r.pos[1] - r.target[1];
+  const double dist = sqrt(dx * dx + dy * dy);
+  const double r_track = (-dist + r.prev_dist) * 100;
+  r.prev_dist = dist;
+  const double ex = -(dx / (dist + 1e-6)), ey = -(dy / (dist + 1e-6));
+  const double vn = sqrt(r.vw[0] * r.vw[0] + r.vw[1] * r.vw[1]);
+  const double r_heading = (r.vw[0] / (vn + 1e-6)) * ex + (r.vw[1] / (vn + 1e-6)) * ey;
+  double rew = r_track + 0.5 * r_heading;
+  bool term = false, trunc = false;
+  if (dist < 0.01) { term = true; rew += 10.0; }
+  else if (dist > 5.0) { trunc = true; rew -= 5.0; }
+  if (r.cycle >= P.max_cycles) trunc = true;
+
+  float o[6];
+  if (term || trunc) {
+    if (final_obs && active) {
+      observe_robot(r, o);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) final_obs[i * 6 + k] = o[k];
+    }
+    reset_robot(r, P, genv);
+  }
+  if (active) {
+    observe_robot(r, o);
+    if (obs) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) obs[i * 6 + k] = o[k];
+    }
+    if (reward) reward[i] = (float)rew;
+    if (terminated) terminated[i] = term ? 1 : 0;
+    if (truncated) truncated[i] = trunc ? 1 : 0;
+    if (inner_steps) inner_steps[i] = steps;
+    store_robot(r, S, P, i);
+  }
+}
+
+thread_local std::string g_rerr;
+int rfail(int code, const std::string& m) { g_rerr = m; return code; }
+#define RHIP_TRY(expr)                                                                              \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) return rfail(_e == hipErrorOutOfMemory ? -4 : -3, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+}  // namespace
+
+struct salp_robot_vec {
+  salp_robot_config_t cfg;
+  RobotParams P;
+  RobotState S;
+  int device;
+  int64_t n;
+  void* stage;
+  size_t stage_bytes;
+};
+
+extern "C" {
+
+const char* salp_robot_last_error(void) { return g_rerr.c_str(); }
+
+int salp_robot_config_default(salp_robot_config_t* c) {
+  if (!c) return rfail(-1, "cfg is NULL");
+  memset(c, 0, sizeof(*c));
+  c->struct_size = (uint32_t)sizeof(*c);
+  c->width = 900; c->height = 700; c->tank_margin = 50.0;
+  c->dry_mass = 1.0; c->init_length = 0.3; c->init_width = 0.15; c->max_contraction = 0.06; c->density = 1000.0;
+  c->dt = 0.01; c->drag_coefficient_min = 0.4; c->drag_coefficient_max = 1.0;
+  c->nozzle_length1 = c->nozzle_length2 = c->nozzle_length3 = 0.05;
+  c->nozzle_area = 0.00016; c->nozzle_mass = 1.0; c->nozzle_gamma = kPi / 4; c->max_cycles = 500;
+  return 0;
+}
+
+int salp_robot_vec_reset(salp_robot_vec_t* h, const uint8_t* mask, float* obs, uint32_t flags, void* stream);
+
+int salp_robot_vec_create(const salp_robot_config_t* cfg, int64_t n_envs, int device_id, uint64_t seed,
+                          int64_t env_index_base, salp_robot_vec_t** out) {
+  if (!out) return rfail(-1, "out is NULL");
+  *out = nullptr;
+  if (!cfg || cfg->struct_size != sizeof(salp_robot_config_t)) return rfail(-1, "salp_robot_config_t.struct_size mismatch");
+  if (n_envs <= 0 || env_index_base < 0) return rfail(-1, "n_envs / env_index_base out of range");
+  if (!(cfg->dt > 0) || !(cfg->init_width > 0) || !(cfg->nozzle_area > 0)) return rfail(-1, "dt, init_width, nozzle_area must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return rfail(-2, "no HIP device visible (this library has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return rfail(-2, "device_id out of range");
+  RHIP_TRY(hipSetDevice(device_id));
+  salp_robot_vec* h = new (std::nothrow) salp_robot_vec();
+  if (!h) return rfail(-4, "host allocation failed");
+  memset(h, 0, sizeof(*h));
+  h->cfg = *cfg; h->device = device_id; h->n = n_envs;
+  RobotParams& P = h->P;
+  P.dry_mass = cfg->dry_mass; P.init_length = cfg->init_length; P.init_width = cfg->init_width;
+  P.max_contraction = cfg->max_contraction; P.density = cfg->density; P.dt = cfg->dt;
+  P.cd_min = cfg->drag_coefficient_min; P.cd_max = cfg->drag_coefficient_max;
+  P.nz_l1 = cfg->nozzle_length1; P.nz_l2 = cfg->nozzle_length2; P.nz_area = cfg->nozzle_area;
+  P.nz_mass = cfg->nozzle_mass; P.nz_gamma = cfg->nozzle_gamma;
+  const double scale = 200.0;
+  P.x_min = (-(double)cfg->width / 2 + cfg->tank_margin) / scale;
+  P.x_span = ((double)cfg->width / 2 - cfg->tank_margin) / scale - P.x_min;
+  P.y_min = (-(double)cfg->height / 2 + cfg->tank_margin) / scale;
+  P.y_span = ((double)cfg->height / 2 - cfg->tank_margin) / scale - P.y_min;
+  P.max_cycles = cfg->max_cycles;
+  P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
+  P.env_base = (uint64_t)env_index_base; P.n = n_envs; P.pitch = (n_envs + 63) / 64 * 64;
+  const size_t bytes = (size_t)SALP_R_COUNT * (size_t)P.pitch * sizeof(double);
+  hipError_t e = hipMalloc((void**)&h->S.f, bytes);
+  if (e == hipSuccess) e = hipMemset(h->S.f, 0, bytes);
+  if (e != hipSuccess) { std::string m = std::string("state allocation: ") + hipGetErrorString(e); salp_robot_vec_destroy(h); return rfail(-4, m); }
+  int rc = salp_robot_vec_reset(h, nullptr, nullptr, 1u, nullptr);   // train_robot.py:16 angles (0, 0) are the zeroed rows
+  if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = rfail(-3, "initial reset failed");
+  if (rc != 0) { std::string m = g_rerr; salp_robot_vec_destroy(h); g_rerr = m; return rc; }
+  *out = h;
+  return 0;
+}
+
+void salp_robot_vec_destroy(salp_robot_vec_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->S.f) (void)hipFree(h->S.f);
+  if (h->stage) (void)hipFree(h->stage);
+  delete h;
+}
+
+int64_t salp_robot_vec_num_envs(const salp_robot_vec_t* h) { return h ? h->n : 0; }
+
+static int robot_stage(salp_robot_vec* h, size_t bytes) {
+  if (bytes <= h->stage_bytes) return 0;
+  if (h->stage) { (void)hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+  RHIP_TRY(hipMalloc(&h->stage, bytes));
+  h->stage_bytes = bytes;
+  return 0;
+}
+
+int salp_robot_vec_reset(salp_robot_vec_t* h, const uint8_t* mask, float* obs, uint32_t flags, void* stream) {
+  if (!h) return rfail(-1, "handle is NULL");
+  RHIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((h->n + kRBlock - 1) / kRBlock);
+  if (flags & 1u) {
+    hipLaunchKernelGGL(salp_robot_reset_kernel, dim3(grid), dim3(kRBlock), 0, st, h->P, h->S, mask, obs, 1);
+    RHIP_TRY(hipGetLastError());
+    return 0;
+  }
+  const size_t ob = (size_t)h->n * 6 * sizeof(float);
+  int rc = robot_stage(h, ob + (size_t)h->n + 1024);
+  if (rc) return rc;
+  float* d_obs = (float*)h->stage;
+  uint8_t* d_mask = (uint8_t*)h->stage + ((ob + 255) / 256) * 256;
+  if (mask) RHIP_TRY(hipMemcpyAsync(d_mask, mask, (size_t)h->n, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(salp_robot_reset_kernel, dim3(grid), dim3(kRBlock), 0, st, h->P, h->S, mask ? (const uint8_t*)d_mask : nullptr,
+                     obs ? d_obs : nullptr, 1);
+  RHIP_TRY(hipGetLastError());
+  if (obs) RHIP_TRY(hipMemcpyAsync(obs, d_obs, ob, hipMemcpyDeviceToHost, st));
+  RHIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+int salp_robot_vec_step(salp_robot_vec_t* h, const float* act, float* obs, float* reward, uint8_t* terminated,
+                        uint8_t* truncated, float* final_obs, int32_t* inner_steps, uint32_t flags, void* stream) {
+  if (!h || !act) return rfail(-1, "handle / act is NULL");
+  RHIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((h->n + kRBlock - 1) / kRBlock);
+  if (flags & 1u) {
+    hipLaunchKernelGGL(salp_robot_step_kernel, dim3(grid), dim3(kRBlock), 0, st, h->P, h->S, act, obs, reward, terminated,
+                       truncated, final_obs, inner_steps);
+    RHIP_TRY(hipGetLastError());
+    return 0;
+  }
+  const size_t n = (size_t)h->n;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t need = up(n * 12) + 2 * up(n * 24) + up(n * 4) + 2 * up(n) + up(n * 4) + 1024;
+  int rc = robot_stage(h, need);
+  if (rc) return rc;
+  char* b = (char*)h->stage;
+  float* d_act = (float*)b; b += up(n * 12);
+  float* d_obs = (float*)b; b += up(n * 24);
+  float* d_fin = (float*)b; b += up(n * 24);
+  float* d_rew = (float*)b; b += up(n * 4);
+  uint8_t* d_te = (uint8_t*)b; b += up(n);
+  uint8_t* d_tr = (uint8_t*)b; b += up(n);
+  int32_t* d_in = (int32_t*)b;
+  RHIP_TRY(hipMemcpyAsync(d_act, act, n * 12, hipMemcpyHostToDevice, st));
+  if (final_obs) RHIP_TRY(hipMemcpyAsync(d_fin, final_obs, n * 24, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(salp_robot_step_kernel, dim3(grid), dim3(kRBlock), 0, st, h->P, h->S, (const float*)d_act, obs ? d_obs : nullptr,
+                     reward ? d_rew : nullptr, terminated ? d_te : nullptr, truncated ? d_tr : nullptr,
+                     final_obs ? d_fin : nullptr, inner_steps ? d_in : nullptr);
+  RHIP_TRY(hipGetLastError());
+  if (obs) RHIP_TRY(hipMemcpyAsync(obs, d_obs, n * 24, hipMemcpyDeviceToHost, st));
+  if (final_obs) RHIP_TRY(hipMemcpyAsync(final_obs, d_fin, n * 24, hipMemcpyDeviceToHost, st));
+  if (reward) RHIP_TRY(hipMemcpyAsync(reward, d_rew, n * 4, hipMemcpyDeviceToHost, st));
+  if (terminated) RHIP_TRY(hipMemcpyAsync(terminated, d_te, n, hipMemcpyDeviceToHost, st));
+  if (truncated) RHIP_TRY(hipMemcpyAsync(truncated, d_tr, n, hipMemcpyDeviceToHost, st));
+  if (inner_steps) RHIP_TRY(hipMemcpyAsync(inner_steps, d_in, n * 4, hipMemcpyDeviceToHost, st));
+  RHIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+int salp_robot_vec_get_state(salp_robot_vec_t* h, double* state, uint32_t flags, void* stream) {
+  if (!h || !state) return rfail(-1, "handle / state is NULL");
+  RHIP_TRY(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  // rows are [pitch] on the device and [n] in the snapshot
+  RHIP_TRY(hipMemcpy2DAsync(state, (size_t)h->n * sizeof(double), h->S.f, (size_t)h->P.pitch * sizeof(double),
+                            (size_t)h->n * sizeof(double), SALP_R_COUNT,
+                            (flags & 1u) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+  if (!(flags & 1u)) RHIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // extern "C"
