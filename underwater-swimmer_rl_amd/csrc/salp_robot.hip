@@ -55,6 +55,14 @@ struct Rb {   // one robot in registers
 };
 
 __device__ __forceinline__ double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// sin/cos of an Euler angle.  The angles are unbounded (yaw winds up), but stay far below 2^20 * pi/2,
+// where the two-constant Cody-Waite reduction of sincos_small (salp_device.h) is exact in its first
+// product; beyond 1e5 rad (never seen; wave-uniform test) the libm-grade routine takes over.
+__device__ __forceinline__ void sincos_euler(double x, double& s, double& c) {
+  if (__any(fabs(x) > 1.0e5)) { sincos(x, &s, &c); return; }
+  sincos_small(x, s, c);
+}
 __device__ __forceinline__ double sq(double x) { return x * x; }
 
 __device__ __forceinline__ void load_robot(Rb& r, const RobotState& S, const RobotParams& P, int64_t i) {
@@ -271,8 +279,8 @@ __global__ __launch_bounds__(kRBlock) void salp_robot_step_kernel(RobotParams P,
       r.om[0] += al0 * dt; r.om[1] += al1 * dt; r.om[2] += al2 * dt;
       {
         double sp, cp, st, ct;
-        sincos(r.eul[0], &sp, &cp);
-        sincos(r.eul[1], &st, &ct);
+        sincos_euler(r.eul[0], sp, cp);
+        sincos_euler(r.eul[1], st, ct);
         const double tt = st / ct;
         const double e0 = r.om[0] + (sp * tt) * r.om[1] + (cp * tt) * r.om[2];
         const double e1 = cp * r.om[1] + (-sp) * r.om[2];
@@ -281,9 +289,9 @@ __global__ __launch_bounds__(kRBlock) void salp_robot_step_kernel(RobotParams P,
       }
       {
         double sp, cp, st, ct, ss, cs;
-        sincos(r.eul[0], &sp, &cp);
-        sincos(r.eul[1], &st, &ct);
-        sincos(r.eul[2], &ss, &cs);
+        sincos_euler(r.eul[0], sp, cp);
+        sincos_euler(r.eul[1], st, ct);
+        sincos_euler(r.eul[2], ss, cs);
         // R = R_z @ R_y @ R_x
         const double r00 = cs * ct, r01 = cs * st * sp - ss * cp, r02 = cs * st * cp + ss * sp;
         const double r10 = ss * ct, r11 = ss * st * sp + cs * cp, r12 = ss * st * cp - cs * sp;
