@@ -184,6 +184,50 @@ class SalpVectorEnv:
                 np.logical_or(c["term"], c["trunc"], out=c["done"])
         return c["obs"], c["rew"], c["term"], c["trunc"], c["info"]
 
+    def capture_policy_steps(self, policy, n_steps: int = 1, record=None, want_final_observation: bool = True):
+        """Captures `n_steps` x (`policy(obs) -> actions`, `step(actions)`) into one hipGraph and returns the
+        `torch.cuda.CUDAGraph`; every `replay()` advances all envs by `n_steps`.  For small batches the
+        acting loop is launch-bound (one step kernel runs in a few microseconds), and a replay costs one
+        host call whatever `n_steps` is.  `record(k, obs, actions, reward, terminated, truncated, info)`,
+        if given, is called inside the capture after step k (e.g. to copy the transition into
+        preallocated replay storage with torch ops); `obs` is the observation the policy saw (a clone).
+        The body runs once un-captured as a warm-up (so does `record`); the env state is restored after it.
+        `salp_vec_step` with device pointers is only kernel launches on the caller's stream, so it is
+        capturable; device-generated actions (`rollout(actions=None)`) are not, their step index lives
+        on the host.  After a replay the env's step outputs (`step`'s return buffers) hold the last step."""
+        t = self._torch
+        if t is None:
+            raise _capi.SalpError("capture_policy_steps needs output='torch'")
+        if getattr(self, "_step_cache", None) is None:
+            self._prepare_step()
+        c = self._step_cache
+        obs = c["obs"]
+
+        def body():
+            for k in range(int(n_steps)):
+                seen = obs.clone() if record is not None else obs
+                a = policy(seen).to(t.float32).reshape(self.num_envs, self.act_dim).contiguous()
+                o, r, te, tr, info = self.step(a, want_final_observation=want_final_observation)
+                if record is not None:
+                    record(k, seen, a, r, te, tr, info)
+
+        # warm-up on a side stream (allocator pools, lazy kernel loads), then restore the envs
+        f64, i32 = self.get_state()
+        obs0 = obs.clone()
+        side = t.cuda.Stream(device=self.device)
+        side.wait_stream(t.cuda.current_stream(self.device))
+        with t.cuda.stream(side):
+            body()
+        t.cuda.current_stream(self.device).wait_stream(side)
+        t.cuda.synchronize(self.device)
+        self.set_state(f64, i32)
+        obs.copy_(obs0)
+        g = t.cuda.CUDAGraph()
+        with t.cuda.graph(g):
+            body()
+        # capture does not execute: state and obs are still those of before the call
+        return g
+
     def rollout(self, actions=None, horizon: Optional[int] = None, want_obs: bool = True,
                 want_final_observation: bool = False, out: Optional[dict] = None) -> dict:
         """`horizon` steps in one kernel launch.  actions: [H, N, act_dim] or None (device-generated)."""
