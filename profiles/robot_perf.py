@@ -29,5 +29,7 @@ def run(n, coast_hi, iters=6):
             "euler_steps_per_s": tot_inner / sec, "mean_inner_steps": tot_inner / (n * iters), "max_inner_steps": max_inner}
 
 if __name__ == "__main__":
-    for n, c in ((65536, 0.1), (262144, 0.1), (262144, 1.0)):
-        print(json.dumps(run(n, c)))
+    for sched in ("0", "1"):          # index order vs longest-cycle-first walk (robot_schedule_* in salp_robot.hip)
+        os.environ["SALP_ROBOT_SCHEDULE"] = sched
+        for n, c in ((65536, 0.1), (262144, 0.1), (262144, 1.0)):
+            print(json.dumps({"schedule": int(sched), **run(n, c)}), flush=True)

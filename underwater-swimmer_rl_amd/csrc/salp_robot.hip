@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include <new>
 #include <string>
@@ -56,14 +57,41 @@ struct Rb {   // one robot in registers
 
 __device__ __forceinline__ double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-// sin/cos of an Euler angle.  The angles are unbounded (yaw winds up), but stay far below 2^20 * pi/2,
-// where the two-constant Cody-Waite reduction of sincos_small (salp_device.h) is exact in its first
-// product; beyond 1e5 rad (never seen; wave-uniform test) the libm-grade routine takes over.
+// sin/cos of an Euler angle.  The angles are unbounded (yaw winds up).  sincos_small (salp_device.h)
+// reduces by pi/2 with fused multiply-adds against a 33 + 53 bit split of pi/2 and keeps the quadrant in
+// an int, good to |x| ~ 1e9; past 1e8 rad (never seen; wave-uniform test) the angle is first folded
+// into [-pi, pi] against a double-double 2*pi, which holds to < 1e-16 rad up to |x| ~ 1e15.
 __device__ __forceinline__ void sincos_euler(double x, double& s, double& c) {
-  if (__any(fabs(x) > 1.0e5)) { sincos(x, &s, &c); return; }
+  if (__any(fabs(x) > 1.0e8)) {
+    const double k = __builtin_rint(x * 0.15915494309189535);
+    x = fma(-k, 2.4492935982947064e-16, fma(-k, 6.283185307179586, x));
+  }
   sincos_small(x, s, c);
 }
 __device__ __forceinline__ double sq(double x) { return x * x; }
+
+// 1/x for a normal, finite x: v_rcp_f64 and two Newton steps (<= 1 ulp; no range scaling / fix-up pass)
+__device__ __forceinline__ double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-x, y, 1.0);
+  return fma(y, e, y);
+}
+// sqrt(x) for x = 0 or x well inside the normal range: v_rsq_f64, one coupled Newton step and a final
+// residual correction (<= 1 ulp); tiny arguments take the library routine
+__device__ __forceinline__ double sqrt_nr(double x) {
+  if (__any(x < 1.0e-200 && x != 0.0)) return sqrt(x);
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double rr = fma(-h, g, 0.5);
+  g = fma(g, rr, g); h = fma(h, rr, h);
+  const double rr2 = fma(-h, g, 0.5);
+  g = fma(g, rr2, g); h = fma(h, rr2, h);
+  const double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return x == 0.0 ? 0.0 : g;
+}
 
 __device__ __forceinline__ void load_robot(Rb& r, const RobotState& S, const RobotParams& P, int64_t i) {
   const int64_t p = P.pitch;
@@ -104,15 +132,6 @@ __device__ __forceinline__ void inertia_diag(const RobotParams& P, double mass, 
   I[0] = 0.2 * mass * (hw2 + hw2);
   I[1] = 0.2 * mass * (hl2 + hw2) + In;
   I[2] = 0.2 * mass * (hw2 + hl2) + In;
-}
-__device__ __forceinline__ double drag_coefficient(const RobotParams& P, double length, double width) {  // robot.py:627-649
-  const double aspect = length / width;
-  const double init_aspect = P.init_length / P.init_width;
-  const double cl = P.init_length - P.max_contraction;
-  const double cw = P.init_length - cl + P.init_width;
-  const double min_aspect = cl / cw;
-  const double nr = clipd((aspect - min_aspect) / (init_aspect - min_aspect), 0.0, 1.0);
-  return P.cd_max - nr * (P.cd_max - P.cd_min);
 }
 // |r_nozzle + r_robot|: R_br @ (base + R_mb @ middle) = (-(l1 + l2), 0, 0) for any joint angles
 // (R_mb turns about z, the links lie on z; robot.py:132-151, 567-575)
@@ -157,13 +176,61 @@ __global__ __launch_bounds__(kRBlock) void salp_robot_reset_kernel(RobotParams P
   }
 }
 
+
+// ---- cycle-length schedule ----------------------------------------------------------------------------
+// A cycle lasts (50 + 25) * contraction + coast seconds, anything from 0 to 14.5 s (0..1450 Euler steps)
+// depending on the action, and a wavefront runs until its slowest lane is done: with envs in index order
+// about half the lane-steps are idle.  A counting sort on the step count (2048 bins, longest first) gives
+// the order the step kernel walks the envs in; three tiny launches, no host round trip.
+constexpr int kSchedBins = 2048;
+
+__device__ __forceinline__ int schedule_bin(const RobotParams& P, const float* act, int64_t i) {
+  const double contraction = (double)act[i * 3 + 0] * 0.06;
+  const double total = contraction * (3.0 / 0.06 + 1.5 / 0.06) + (double)act[i * 3 + 1] * 10.0;
+  const double steps = total / P.dt * ((kSchedBins - 1) / (14.5 / P.dt + 1.0));
+  if (!(steps > 0.0)) return 0;
+  return steps >= (double)(kSchedBins - 1) ? kSchedBins - 1 : (int)steps;
+}
+__global__ __launch_bounds__(kRBlock) void robot_schedule_count(RobotParams P, const float* act, uint32_t* bins) {
+  const int64_t i = (int64_t)blockIdx.x * kRBlock + threadIdx.x;
+  if (i < P.n) atomicAdd(&bins[schedule_bin(P, act, i)], 1u);
+}
+// bins[k] <- number of envs in bins above k (longest cycles get the first positions)
+__global__ __launch_bounds__(1024) void robot_schedule_scan(uint32_t* bins) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const int hi = kSchedBins - 1 - 2 * t, lo = hi - 1;     // thread t owns bins hi, lo (descending order)
+  const uint32_t c_hi = bins[hi], c_lo = bins[lo];
+  part[t] = c_hi + c_lo;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t v = t >= d ? part[t - d] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  const uint32_t before = part[t] - (c_hi + c_lo);
+  bins[hi] = before;
+  bins[lo] = before + c_hi;
+}
+__global__ __launch_bounds__(kRBlock) void robot_schedule_scatter(RobotParams P, const float* act, uint32_t* bins, int32_t* order) {
+  const int64_t i = (int64_t)blockIdx.x * kRBlock + threadIdx.x;
+  if (i < P.n) order[atomicAdd(&bins[schedule_bin(P, act, i)], 1u)] = (int32_t)i;
+}
+
 // SalpRobotEnv.step (salp_robot_env.py:139-201): one breathing cycle per env.
-__global__ __launch_bounds__(kRBlock) void salp_robot_step_kernel(RobotParams P, RobotState S, const float* act, float* obs,
+#ifndef SALP_ROBOT_WAVES
+#define SALP_ROBOT_WAVES 2
+#endif
+__global__ __launch_bounds__(kRBlock) __attribute__((amdgpu_waves_per_eu(SALP_ROBOT_WAVES, SALP_ROBOT_WAVES)))
+void salp_robot_step_kernel(RobotParams P, RobotState S, const float* act, float* obs,
                                                                   float* reward, uint8_t* terminated, uint8_t* truncated,
-                                                                  float* final_obs, int32_t* inner_steps) {
+                                                                  float* final_obs, int32_t* inner_steps, const int32_t* order) {
   const int64_t i0 = (int64_t)blockIdx.x * kRBlock + threadIdx.x;
   const bool active = i0 < P.n;
-  const int64_t i = active ? i0 : (P.n - 1);
+  // `order` (robot_schedule_* below) lists the envs longest cycle first, so that the lanes of a wavefront
+  // run about the same number of Euler steps; results do not depend on which lane an env runs in.
+  const int64_t i = active ? (order ? (int64_t)order[i0] : i0) : (P.n - 1);
   const uint64_t genv = P.env_base + (uint64_t)i;
   Rb r;
   load_robot(r, S, P, i);
@@ -172,15 +239,20 @@ __global__ __launch_bounds__(kRBlock) void salp_robot_step_kernel(RobotParams P,
   const double contraction = (double)act[i * 3 + 0] * 0.06;
   const double coast_time = (double)act[i * 3 + 1] * 10.0;
   const double yaw = (double)act[i * 3 + 2] * (kPi / 2);
-  // Nozzle.solve_angles (robot.py:55-85): target = R_br^T @ -(cos yaw, sin yaw, 0) = (-0, -sin yaw, cos yaw)
+  // Nozzle.solve_angles (robot.py:55-85): target = R_br^T @ -(cos yaw, sin yaw, 0) = (-0, -sin yaw, cos yaw).
+  // Every angle here is within [-pi, pi]: sincos_small (salp_device.h) is exact to < 1 ulp there.
   {
-    const double t1 = -sin(yaw), t2 = cos(yaw);
+    double sy, cy;
+    sincos_small(yaw, sy, cy);
+    const double t1 = -sy, t2 = cy;
     double a2 = acos(clipd(2 * t2 - 1, -1.0, 1.0));
     if (a2 <= -kPi) a2 += 2 * kPi; else if (a2 > kPi) a2 -= 2 * kPi;
     double a1 = 0.0;
     if (a2 != 0.0) {
-      const double a = 0.5 * (cos(a2) - 1);
-      const double b = sqrt(2.0) * sin(a2) / 2;
+      double sa2, ca2;
+      sincos_small(a2, sa2, ca2);
+      const double a = 0.5 * (ca2 - 1);
+      const double b = sqrt(2.0) * sa2 / 2;
       a1 = asin(clipd(t1 / sqrt(a * a + b * b), -1.0, 1.0)) - atan2(b, a);
     }
     if (a1 <= -kPi) a1 += 2 * kPi; else if (a1 > kPi) a1 -= 2 * kPi;
@@ -189,8 +261,10 @@ __global__ __launch_bounds__(kRBlock) void salp_robot_step_kernel(RobotParams P,
   // Nozzle.get_nozzle_direction (robot.py:115-130): R_br @ R_mb @ R_nm @ (cos g, 0, sin g), constant over the cycle
   double dir[3];
   {
-    const double g = P.nz_gamma, cg = cos(g), sg = sin(g);
-    const double c2 = cos(r.angle2), s2 = sin(r.angle2), c1 = cos(r.angle1), s1 = sin(r.angle1);
+    double cg, sg, c2, s2, c1, s1;
+    sincos_small(P.nz_gamma, sg, cg);
+    sincos_small(r.angle2, s2, c2);
+    sincos_small(r.angle1, s1, c1);
     // R_nm = R_theta_fixed @ R_nozzle(angle2); v1 = R_nm @ (cg, 0, sg)
     const double nx = (cg * c2) * cg + (-sg) * sg;
     const double ny = s2 * cg;
@@ -205,12 +279,30 @@ __global__ __launch_bounds__(kRBlock) void salp_robot_step_kernel(RobotParams P,
   const double contract_rate = 0.06 / 3, release_rate = 0.06 / 1.5;
   const double refill_time = contraction / contract_rate;
   const double jet_time = contraction / release_rate;
-  const double total = refill_time + jet_time + coast_time;
+  const double total = active ? refill_time + jet_time + coast_time : 0.0;   // padding lanes do not step
   double cycle_time = 0.0;
   int steps = 0;
   const double dt = P.dt;
 
-  // Robot.step_through_cycle (robot.py:422-445): lanes finish at different times
+  // Robot.step_through_cycle (robot.py:422-445): lanes finish at different times.
+  //  * quantities that depend only on the body shape (mass, inertia, drag factors and their reciprocals)
+  //    are kept in registers and recomputed only on a step where some lane's shape moves or has just
+  //    stopped moving; during coast / rest (most of a cycle) the whole wavefront skips that block;
+  //  * sin/cos of roll and pitch after the kinematic update are the ones the next step starts with;
+  //  * divisions by dt, by cos(pitch) and by the mass / inertia diagonal are reciprocals (Newton-refined
+  //    v_rcp_f64) times a product: a few ulp from the reference's quotient, far inside the parity
+  //    tolerance, which is a tolerance already because the reference multiplies 3x3 blocks through BLAS.
+  const double inv_dt = rcp_nr(dt);
+  const double init_aspect = P.init_length / P.init_width;
+  const double contracted_length = P.init_length - P.max_contraction;
+  const double min_aspect = contracted_length / (P.init_length - contracted_length + P.init_width);
+  const double inv_aspect_span = rcp_nr(init_aspect - min_aspect);
+  const double t_jet_end = refill_time + jet_time, t_coast_end = t_jet_end + coast_time;
+  double mass = 0, inv_m = 0, kd = 0, ktc = 0, ax = 0, I0 = 0, I1 = 0, I2 = 0, iI0 = 0, iI1 = 0, iI2 = 0;
+  bool settled = false;    // the previous step of this lane already had the rest shape (and prevI == I)
+  double sp, cp, st, ct;
+  sincos_euler(r.eul[0], sp, cp);
+  sincos_euler(r.eul[1], st, ct);
 #pragma unroll 1
   while (__any(cycle_time < total)) {
     if (cycle_time < total) {
@@ -219,76 +311,84 @@ __global__ __launch_bounds__(kRBlock) void salp_robot_step_kernel(RobotParams P,
       r.time += dt;
       int state;   // update_state :360-373
       if (cycle_time <= refill_time) state = 0;
-      else if (cycle_time <= refill_time + jet_time) state = 1;
-      else if (cycle_time <= refill_time + jet_time + coast_time) state = 2;
+      else if (cycle_time <= t_jet_end) state = 1;
+      else if (cycle_time <= t_coast_end) state = 2;
       else state = 3;
-      // update_properties :375-385
-      const double prev_volume = r.volume;
-      const double prev_water_mass = prev_volume * P.density;
-      double length, width;
-      if (state == 0) { length = P.init_length - cycle_time * contract_rate; width = P.init_width + cycle_time * contract_rate; }
-      else if (state == 1) {
-        length = P.init_length - contraction + (cycle_time - refill_time) * release_rate;
-        width = P.init_width + contraction - (cycle_time - refill_time) * release_rate;
-      } else { length = P.init_length; width = P.init_width; }
-      const double area = kPi * (length / 2) * (width / 2);
-      r.volume = water_volume(length, width);
-      const double water_mass = P.density * r.volume;
-      const double mass = P.dry_mass + water_mass + P.nz_mass;
-      const double cd = drag_coefficient(P, length, width);
+      double jf0 = 0.0, jf1 = 0.0, jf2 = 0.0, td0 = 0.0, td1 = 0.0, td2 = 0.0;
+      if (__any(state < 2 || !settled)) {
+        // update_properties :375-385
+        const double prev_volume = r.volume;
+        double length, width;
+        if (state == 0) { length = P.init_length - cycle_time * contract_rate; width = P.init_width + cycle_time * contract_rate; }
+        else if (state == 1) {
+          length = P.init_length - contraction + (cycle_time - refill_time) * release_rate;
+          width = P.init_width + contraction - (cycle_time - refill_time) * release_rate;
+        } else { length = P.init_length; width = P.init_width; }
+        const double hl = length / 2, hw = width / 2;
+        const double area = kPi * hl * hw;
+        r.volume = water_volume(length, width);
+        const double water_mass = P.density * r.volume;
+        mass = P.dry_mass + water_mass + P.nz_mass;
+        inv_m = rcp_nr(mass);
+        // drag coefficient, robot.py:627-649
+        const double aspect = length * rcp_nr(width);
+        const double nr = clipd((aspect - min_aspect) * inv_aspect_span, 0.0, 1.0);
+        const double cd = P.cd_max - nr * (P.cd_max - P.cd_min);
+        kd = -0.5 * P.density * area * cd;
+        ktc = -P.density * cd * hw * sq(sq(hl));
+        if (state == 1) {   // jet force, :494-505
+          const double volume_rate = -(r.volume - prev_volume) * inv_dt;
+          const double jet_speed = volume_rate / P.nz_area;
+          const double mass_rate = (water_mass - prev_volume * P.density) * inv_dt;
+          jf0 = 0.1 * mass_rate * (dir[0] * jet_speed);
+          jf1 = 0.1 * mass_rate * (dir[1] * jet_speed);
+          jf2 = 0.1 * mass_rate * (dir[2] * jet_speed);
+        }
+        ax = arm_x(P, length);
+        double I[3];
+        inertia_diag(P, mass, length, width, ax * ax, I);
+        I0 = I[0]; I1 = I[1]; I2 = I[2];
+        iI0 = rcp_nr(I0); iI1 = rcp_nr(I1); iI2 = rcp_nr(I2);
+        td0 = ((I0 - r.prevI[0]) * inv_dt) * r.om[0];
+        td1 = ((I1 - r.prevI[1]) * inv_dt) * r.om[1];
+        td2 = ((I2 - r.prevI[2]) * inv_dt) * r.om[2];
+        r.prevI[0] = I0; r.prevI[1] = I1; r.prevI[2] = I2;
+        settled = state >= 2;
+      }
       // _newton_equations :494-505
       const double wxv0 = r.om[1] * r.vel[2] - r.om[2] * r.vel[1];
       const double wxv1 = r.om[2] * r.vel[0] - r.om[0] * r.vel[2];
       const double wxv2 = r.om[0] * r.vel[1] - r.om[1] * r.vel[0];
-      const double vnorm = sqrt(r.vel[0] * r.vel[0] + r.vel[1] * r.vel[1] + r.vel[2] * r.vel[2]);
-      const double kd = -0.5 * P.density * area * cd;
+      const double vnorm = sqrt_nr(r.vel[0] * r.vel[0] + r.vel[1] * r.vel[1] + r.vel[2] * r.vel[2]);
       const double kq = kd * vnorm;
-      double jf[3] = {0.0, 0.0, 0.0};
-      if (state == 1) {
-        const double volume_rate = -(r.volume - prev_volume) / dt;
-        const double jet_speed = volume_rate / P.nz_area;
-        const double mass_rate = (water_mass - prev_water_mass) / dt;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) jf[k] = 0.1 * mass_rate * (dir[k] * jet_speed);
-      }
-      const double inv_m = 1.0 / mass;
-      const double acc0 = inv_m * (jf[0] + (kq * r.vel[0] + kd * r.vel[0]) + mass * wxv0);
-      const double acc1 = inv_m * (jf[1] + (kq * r.vel[1] + kd * r.vel[1]) + mass * wxv1);
-      const double acc2 = inv_m * (jf[2] + (kq * r.vel[2] + kd * r.vel[2]) + mass * wxv2);
+      const double acc0 = inv_m * (jf0 + (kq * r.vel[0] + kd * r.vel[0]) + mass * wxv0);
+      const double acc1 = inv_m * (jf1 + (kq * r.vel[1] + kd * r.vel[1]) + mass * wxv1);
+      const double acc2 = inv_m * (jf2 + (kq * r.vel[2] + kd * r.vel[2]) + mass * wxv2);
       // _euler_equations :507-522
-      const double ax = arm_x(P, length);
-      double I[3];
-      inertia_diag(P, mass, length, width, ax * ax, I);
-      const double Iw0 = I[0] * r.om[0], Iw1 = I[1] * r.om[1], Iw2 = I[2] * r.om[2];
+      const double Iw0 = I0 * r.om[0], Iw1 = I1 * r.om[1], Iw2 = I2 * r.om[2];
       const double c0 = r.om[1] * Iw2 - r.om[2] * Iw1;
       const double c1 = r.om[2] * Iw0 - r.om[0] * Iw2;
       const double c2 = r.om[0] * Iw1 - r.om[1] * Iw0;
-      const double wnorm = sqrt(r.om[0] * r.om[0] + r.om[1] * r.om[1] + r.om[2] * r.om[2]);
-      const double kt = -P.density * cd * (width / 2) * sq(sq(length / 2)) * wnorm;
+      const double wnorm = sqrt_nr(r.om[0] * r.om[0] + r.om[1] * r.om[1] + r.om[2] * r.om[2]);
+      const double kt = ktc * wnorm;
       // jet torque = arm x jet_force, arm = (ax, 0, 0)
-      const double jt0 = 0.0, jt1 = -ax * jf[2], jt2 = ax * jf[1];
-      const double td0 = ((I[0] - r.prevI[0]) / dt) * r.om[0];
-      const double td1 = ((I[1] - r.prevI[1]) / dt) * r.om[1];
-      const double td2 = ((I[2] - r.prevI[2]) / dt) * r.om[2];
-      r.prevI[0] = I[0]; r.prevI[1] = I[1]; r.prevI[2] = I[2];
-      const double al0 = (1.0 / I[0]) * (jt0 + kt * r.om[0] + -c0 + 0.0 - td0);
-      const double al1 = (1.0 / I[1]) * (jt1 + kt * r.om[1] + -c1 + 0.0 - td1);
-      const double al2 = (1.0 / I[2]) * (jt2 + kt * r.om[2] + -c2 + 0.1 * vnorm - td2);
+      const double jt1 = -ax * jf2, jt2 = ax * jf1;
+      const double al0 = iI0 * (kt * r.om[0] + -c0 - td0);
+      const double al1 = iI1 * (jt1 + kt * r.om[1] + -c1 - td1);
+      const double al2 = iI2 * (jt2 + kt * r.om[2] + -c2 + 0.1 * vnorm - td2);
       // _update_motion_states :524-532
       r.vel[0] += acc0 * dt; r.vel[1] += acc1 * dt; r.vel[2] += acc2 * dt;
       r.om[0] += al0 * dt; r.om[1] += al1 * dt; r.om[2] += al2 * dt;
       {
-        double sp, cp, st, ct;
-        sincos_euler(r.eul[0], sp, cp);
-        sincos_euler(r.eul[1], st, ct);
-        const double tt = st / ct;
+        const double ict = rcp_nr(ct);
+        const double tt = st * ict;
         const double e0 = r.om[0] + (sp * tt) * r.om[1] + (cp * tt) * r.om[2];
         const double e1 = cp * r.om[1] + (-sp) * r.om[2];
-        const double e2 = (sp / ct) * r.om[1] + (cp / ct) * r.om[2];
+        const double e2 = (sp * ict) * r.om[1] + (cp * ict) * r.om[2];
         r.eul[0] += e0 * dt; r.eul[1] += e1 * dt; r.eul[2] += e2 * dt;
       }
       {
-        double sp, cp, st, ct, ss, cs;
+        double ss, cs;
         sincos_euler(r.eul[0], sp, cp);
         sincos_euler(r.eul[1], st, ct);
         sincos_euler(r.eul[2], ss, cs);
@@ -360,7 +460,31 @@ struct salp_robot_vec {
   int64_t n;
   void* stage;
   size_t stage_bytes;
+  uint32_t* bins;     // [kSchedBins]
+  int32_t* order;     // [n]
+  bool schedule;      // walk the envs longest cycle first (see robot_schedule_*)
 };
+
+// Below this many envs every wavefront has an execution unit to itself and the launch lasts as long as
+// its slowest env whatever the order.  SALP_ROBOT_SCHEDULE=0/1 overrides (tests run both ways).
+static const int64_t kScheduleMinEnvs = 32768;
+
+static int launch_robot_step(salp_robot_vec* h, const float* act, float* obs, float* reward, uint8_t* terminated,
+                             uint8_t* truncated, float* final_obs, int32_t* inner_steps, hipStream_t st) {
+  const unsigned grid = (unsigned)((h->n + kRBlock - 1) / kRBlock);
+  const int32_t* order = nullptr;
+  if (h->schedule) {
+    RHIP_TRY(hipMemsetAsync(h->bins, 0, kSchedBins * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(robot_schedule_count, dim3(grid), dim3(kRBlock), 0, st, h->P, act, h->bins);
+    hipLaunchKernelGGL(robot_schedule_scan, dim3(1), dim3(1024), 0, st, h->bins);
+    hipLaunchKernelGGL(robot_schedule_scatter, dim3(grid), dim3(kRBlock), 0, st, h->P, act, h->bins, h->order);
+    order = h->order;
+  }
+  hipLaunchKernelGGL(salp_robot_step_kernel, dim3(grid), dim3(kRBlock), 0, st, h->P, h->S, act, obs, reward, terminated,
+                     truncated, final_obs, inner_steps, order);
+  RHIP_TRY(hipGetLastError());
+  return 0;
+}
 
 extern "C" {
 
@@ -412,6 +536,11 @@ int salp_robot_vec_create(const salp_robot_config_t* cfg, int64_t n_envs, int de
   const size_t bytes = (size_t)SALP_R_COUNT * (size_t)P.pitch * sizeof(double);
   hipError_t e = hipMalloc((void**)&h->S.f, bytes);
   if (e == hipSuccess) e = hipMemset(h->S.f, 0, bytes);
+  h->schedule = n_envs >= kScheduleMinEnvs;
+  if (const char* ev = getenv("SALP_ROBOT_SCHEDULE")) h->schedule = ev[0] == '1';
+  if (n_envs > INT32_MAX) h->schedule = false;
+  if (e == hipSuccess && h->schedule) e = hipMalloc((void**)&h->bins, kSchedBins * sizeof(uint32_t));
+  if (e == hipSuccess && h->schedule) e = hipMalloc((void**)&h->order, (size_t)n_envs * sizeof(int32_t));
   if (e != hipSuccess) { std::string m = std::string("state allocation: ") + hipGetErrorString(e); salp_robot_vec_destroy(h); return rfail(-4, m); }
   int rc = salp_robot_vec_reset(h, nullptr, nullptr, 1u, nullptr);   // train_robot.py:16 angles (0, 0) are the zeroed rows
   if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = rfail(-3, "initial reset failed");
@@ -425,6 +554,8 @@ void salp_robot_vec_destroy(salp_robot_vec_t* h) {
   (void)hipSetDevice(h->device);
   if (h->S.f) (void)hipFree(h->S.f);
   if (h->stage) (void)hipFree(h->stage);
+  if (h->bins) (void)hipFree(h->bins);
+  if (h->order) (void)hipFree(h->order);
   delete h;
 }
 
@@ -467,13 +598,7 @@ int salp_robot_vec_step(salp_robot_vec_t* h, const float* act, float* obs, float
   if (!h || !act) return rfail(-1, "handle / act is NULL");
   RHIP_TRY(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  const unsigned grid = (unsigned)((h->n + kRBlock - 1) / kRBlock);
-  if (flags & 1u) {
-    hipLaunchKernelGGL(salp_robot_step_kernel, dim3(grid), dim3(kRBlock), 0, st, h->P, h->S, act, obs, reward, terminated,
-                       truncated, final_obs, inner_steps);
-    RHIP_TRY(hipGetLastError());
-    return 0;
-  }
+  if (flags & 1u) return launch_robot_step(h, act, obs, reward, terminated, truncated, final_obs, inner_steps, st);
   const size_t n = (size_t)h->n;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t need = up(n * 12) + 2 * up(n * 24) + up(n * 4) + 2 * up(n) + up(n * 4) + 1024;
@@ -489,10 +614,9 @@ int salp_robot_vec_step(salp_robot_vec_t* h, const float* act, float* obs, float
   int32_t* d_in = (int32_t*)b;
   RHIP_TRY(hipMemcpyAsync(d_act, act, n * 12, hipMemcpyHostToDevice, st));
   if (final_obs) RHIP_TRY(hipMemcpyAsync(d_fin, final_obs, n * 24, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(salp_robot_step_kernel, dim3(grid), dim3(kRBlock), 0, st, h->P, h->S, (const float*)d_act, obs ? d_obs : nullptr,
-                     reward ? d_rew : nullptr, terminated ? d_te : nullptr, truncated ? d_tr : nullptr,
-                     final_obs ? d_fin : nullptr, inner_steps ? d_in : nullptr);
-  RHIP_TRY(hipGetLastError());
+  rc = launch_robot_step(h, d_act, obs ? d_obs : nullptr, reward ? d_rew : nullptr, terminated ? d_te : nullptr,
+                         truncated ? d_tr : nullptr, final_obs ? d_fin : nullptr, inner_steps ? d_in : nullptr, st);
+  if (rc) return rc;
   if (obs) RHIP_TRY(hipMemcpyAsync(obs, d_obs, n * 24, hipMemcpyDeviceToHost, st));
   if (final_obs) RHIP_TRY(hipMemcpyAsync(final_obs, d_fin, n * 24, hipMemcpyDeviceToHost, st));
   if (reward) RHIP_TRY(hipMemcpyAsync(reward, d_rew, n * 4, hipMemcpyDeviceToHost, st));
