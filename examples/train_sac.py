@@ -10,7 +10,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import underwater_swimmer_rl_amd as salp
-from underwater_swimmer_rl_amd.sac import SAC, SACConfig, train_sac
+from underwater_swimmer_rl_amd.sac import SAC, SACConfig, train_sac, train_sac_graphed
 
 
 def main():
@@ -22,13 +22,19 @@ def main():
     ap.add_argument("--updates-per-step", type=int, default=1)
     ap.add_argument("--stop-at-first-food", action="store_true")
     ap.add_argument("--log-every", type=int, default=200)
+    ap.add_argument("--eager", action="store_true", help="issue every kernel from Python (train_sac) instead of "
+                    "one hipGraph replay per vector step (train_sac_graphed)")
     args = ap.parse_args()
     env = salp.SalpVectorEnv(args.preset, num_envs=args.envs, device="cuda:0", seed=0)
     cfg = SACConfig.from_preset(args.preset)
     cfg.learning_starts, cfg.updates_per_step = args.learning_starts, args.updates_per_step
     agent = SAC(env.obs_dim, env.act_dim, cfg, device="cuda:0", seed=0,
                 act_low=env.single_action_space.low, act_high=env.single_action_space.high)
-    m = train_sac(env, agent, args.steps, log_every=args.log_every, stop_at_first_food=args.stop_at_first_food)
+    if args.eager:
+        m = train_sac(env, agent, args.steps, log_every=args.log_every, stop_at_first_food=args.stop_at_first_food)
+    else:
+        m = train_sac_graphed(env, agent, args.steps, stop_at_first_food=args.stop_at_first_food)
+    m["mode"] = "eager" if args.eager else "hipgraph"
     m["stats"] = env.stats()
     m["config"] = {"preset": args.preset, "envs": args.envs, "batch_size": cfg.batch_size, "gamma": cfg.gamma}
     print(json.dumps(m))

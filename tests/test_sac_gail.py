@@ -122,3 +122,40 @@ def test_discriminator_on_the_reference_human_demos():
     for _ in range(200):       # "agent" = uniformly random observations / actions
         m = d.update(eb.sample(128), {"observations": torch.rand(128, 24) * 2 - 1, "actions": torch.rand(128, 1) * 2 - 1})
     assert m["discriminator_accuracy"] > 0.9
+
+
+def test_capturable_replay_ops_match_the_eager_ring():
+    """add_capturable / sample_capturable (device-side cursor) against add (Python cursor)."""
+    from underwater_swimmer_rl_amd.sac import DeviceReplayBuffer
+    g = torch.Generator().manual_seed(0)
+    a, b = DeviceReplayBuffer(10, 3, 1, "cpu"), DeviceReplayBuffer(10, 3, 1, "cpu")
+    for _ in range(7):      # wraps several times
+        rows = [torch.randn(4, 3, generator=g), torch.randn(4, 1, generator=g), torch.randn(4, generator=g),
+                torch.randn(4, 3, generator=g), torch.rand(4, generator=g) > 0.5]
+        a.add(*rows)
+        b.add_capturable(*rows); b.advance_host(4)
+        assert (a.pos, a.size) == (b.pos, b.size) == (int(b.pos_t), int(b.size_t))
+        for x, y in ((a.obs, b.obs), (a.act, b.act), (a.rew, b.rew), (a.next_obs, b.next_obs), (a.term, b.term)):
+            assert torch.equal(x[:a.size], y[:b.size])
+    o, ac, r, no, te = b.sample_capturable(64)
+    assert o.shape == (64, 3) and te.shape == (64,)
+
+
+@pytest.mark.gpu
+def test_graphed_sac_training_runs_and_counts_like_the_eager_loop():
+    """train_sac_graphed: one hipGraph replay per vector step; same bookkeeping as train_sac."""
+    import underwater_swimmer_rl_amd as salp
+    from underwater_swimmer_rl_amd.sac import SAC, SACConfig, train_sac_graphed
+    env = salp.SalpVectorEnv("sac_gail", num_envs=512, device="cuda:0", seed=3)
+    cfg = SACConfig.from_preset("sac_gail")
+    cfg.learning_starts = 6
+    agent = SAC(env.obs_dim, env.act_dim, cfg, device="cuda:0", seed=0,
+                act_low=env.single_action_space.low, act_high=env.single_action_space.high)
+    w0 = [p.detach().clone() for p in agent.actor.parameters()]
+    m = train_sac_graphed(env, agent, 40, poll_every=4)
+    assert m["vector_steps"] == 40 and m["env_steps"] == 40 * 512
+    assert m["updates"] == 34 and m["graphs"] == 2          # steps 6..39 learn; one graph per phase
+    assert env.stats()["env_steps"] == 40 * 512             # every replay really stepped the envs
+    assert all(np.isfinite(m[k]) for k in ("critic_loss", "actor_loss", "alpha", "entropy"))
+    assert any(not torch.equal(a, b) for a, b in zip(w0, agent.actor.parameters()))
+    env.close()

@@ -91,6 +91,33 @@ class DeviceReplayBuffer:
         self.rew = torch.empty((self.capacity,), device=device)
         self.term = torch.empty((self.capacity,), device=device)   # 1.0 where the episode TERMINATED (no bootstrap)
         self.pos, self.size = 0, 0
+        # device-side copies of the cursor, used by the capturable variants below
+        self.pos_t = torch.zeros((), dtype=torch.long, device=device)
+        self.size_t = torch.zeros((), dtype=torch.long, device=device)
+
+    # --- hipGraph-capturable variants: no Python-side cursor is baked into the captured kernels ---------
+    @torch.no_grad()
+    def add_capturable(self, obs, act, rew, next_obs, terminated):
+        """Same as `add` for n <= capacity rows, as pure device ops on `pos_t` / `size_t` (the captured
+        graph is replayed with a moving cursor).  Call `advance_host(n)` after each replay / call."""
+        n = obs.shape[0]
+        assert n <= self.capacity
+        idx = (self.pos_t + torch.arange(n, device=self.device)) % self.capacity
+        self.obs.index_copy_(0, idx, obs)
+        self.next_obs.index_copy_(0, idx, next_obs)
+        self.act.index_copy_(0, idx, act)
+        self.rew.index_copy_(0, idx, rew)
+        self.term.index_copy_(0, idx, terminated.to(self.rew.dtype))
+        self.pos_t.add_(n).remainder_(self.capacity)
+        self.size_t.add_(n).clamp_(max=self.capacity)
+
+    def advance_host(self, n):
+        self.pos = (self.pos + n) % self.capacity
+        self.size = min(self.capacity, self.size + n)
+
+    def sample_capturable(self, batch_size):
+        idx = (torch.rand(batch_size, device=self.device) * self.size_t).long().clamp_(max=self.capacity - 1)
+        return self.obs[idx], self.act[idx], self.rew[idx], self.next_obs[idx], self.term[idx]
 
     @torch.no_grad()
     def add(self, obs, act, rew, next_obs, terminated):
@@ -110,6 +137,8 @@ class DeviceReplayBuffer:
             return
         self.pos = end % self.capacity
         self.size = min(self.capacity, self.size + n)
+        self.pos_t.fill_(self.pos)
+        self.size_t.fill_(self.size)
 
     def sample(self, batch_size, generator=None):
         idx = torch.randint(0, self.size, (batch_size,), device=self.device, generator=generator)
@@ -158,13 +187,15 @@ class SAC:
         self.critic_target.load_state_dict(self.critic.state_dict())
         for p in self.critic_target.parameters():
             p.requires_grad_(False)
-        self.actor_opt = torch.optim.Adam(self.actor.parameters(), lr=cfg.learning_rate)
-        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=cfg.learning_rate)
+        # capturable Adam keeps its step count on the device, so `update` can live inside a hipGraph
+        cap = self.device.type == "cuda"
+        self.actor_opt = torch.optim.Adam(self.actor.parameters(), lr=cfg.learning_rate, capturable=cap)
+        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=cfg.learning_rate, capturable=cap)
         # train.py:60-70 leaves ent_coef at SB3's "auto"; SB3SACAgent passes the YAML alpha (fixed)
         self.learn_alpha = (cfg.alpha is None) if learn_alpha is None else learn_alpha
         init_alpha = 1.0 if cfg.alpha is None else float(cfg.alpha)
         self.log_alpha = torch.tensor(math.log(init_alpha), device=self.device, requires_grad=self.learn_alpha)
-        self.alpha_opt = torch.optim.Adam([self.log_alpha], lr=cfg.alpha_lr) if self.learn_alpha else None
+        self.alpha_opt = torch.optim.Adam([self.log_alpha], lr=cfg.alpha_lr, capturable=cap) if self.learn_alpha else None
         self.target_entropy = -float(act_dim) if cfg.target_entropy is None else float(cfg.target_entropy)
         self.updates = 0
 
@@ -272,4 +303,114 @@ def train_sac(env, agent: SAC, total_vector_steps: int, buffer: Optional[DeviceR
     return {"wall_s": wall, "vector_steps": step + 1, "env_steps": (step + 1) * n, "updates": agent.updates,
             "first_food_wall_s": first_food_s, "first_food_vector_step": first_food_step,
             "episodes": finished, "mean_return": finished_returns / max(finished, 1),
+            **{k: float(v) for k, v in last.items()}}
+
+
+def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional[DeviceReplayBuffer] = None,
+                      reward_fn=None, stop_at_first_food: bool = False, poll_every: int = 8,
+                      warmup_iters: int = 3) -> Dict[str, float]:
+    """`train_sac` with one hipGraph replay per vector step.
+
+    One training iteration is ~250 small kernels (policy forward, `salp_vec_step`, replay insert, twin-critic
+    / actor / entropy updates, polyak): issued one by one the host is the bottleneck (~5 ms per iteration at
+    4096 envs, the GPU idle most of the time).  Here the whole iteration — acting, the env step through the
+    C ABI, the buffer insert with a device-side cursor, sampling, the three optimiser steps — is captured
+    once per phase (random actions before `learning_starts`, policy + updates after) and replayed; the host
+    only polls a device flag every `poll_every` steps.  Same algorithm and hyper-parameters as `train_sac`;
+    `reward_fn`, if given, must be capturable (pure device ops, no host reads)."""
+    cfg, dev = agent.cfg, agent.device
+    if dev.type != "cuda":
+        raise RuntimeError("train_sac_graphed needs a ROCm device")
+    n = env.num_envs
+    buffer = buffer or DeviceReplayBuffer(cfg.buffer_size, env.obs_dim, env.act_dim, dev)
+    low = torch.as_tensor(env.single_action_space.low, device=dev)
+    high = torch.as_tensor(env.single_action_space.high, device=dev)
+    obs0, _ = env.reset()
+    obs = obs0.clone()                                   # static input of every graph
+    ep_returns = torch.zeros(n, device=dev)
+    fin_ret = torch.zeros((), device=dev, dtype=torch.float64)
+    fin_cnt = torch.zeros((), device=dev, dtype=torch.long)
+    step_t = torch.zeros((), device=dev, dtype=torch.long)
+    first_t = torch.full((), -1, device=dev, dtype=torch.long)
+    last: Dict[str, torch.Tensor] = {}
+
+    def iteration(random_actions: bool, learn: bool):
+        with torch.no_grad():
+            if random_actions:
+                act = low + (high - low) * torch.rand((n, env.act_dim), device=dev)
+            else:
+                act = agent.act(obs)
+            nobs, rew, term, trunc, info = env.step(act)
+            done = term | trunc
+            next_obs = torch.where(done[:, None], info["final_observation"], nobs)
+            r = rew if reward_fn is None else reward_fn(obs, act, rew)
+            buffer.add_capturable(obs, act, r, next_obs, term)
+            ep_returns.add_(rew)
+            fin_ret.add_((ep_returns * done).sum())
+            fin_cnt.add_(done.sum())
+            ep_returns.mul_(~done)
+            step_t.add_(1)
+            first_t.copy_(torch.where((first_t < 0) & (info["food_collected"] > 0).any(), step_t, first_t))
+            obs.copy_(nobs)
+        if learn:
+            for _ in range(cfg.updates_per_step):
+                out = agent.update(buffer.sample_capturable(cfg.batch_size))
+            for k, v in out.items():
+                if k in last:
+                    last[k].copy_(v)
+                else:
+                    last[k] = v.clone()
+
+    graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
+    warm: Dict[tuple, int] = {}
+    side = torch.cuda.Stream(device=dev)
+    t0 = time.perf_counter()
+    first_food_s, first_food_step = None, None
+    t_learn, learn_from = None, 0
+    step = 0
+    while step < total_vector_steps:
+        random_actions = step < cfg.learning_starts
+        learn = (not random_actions) and buffer.size >= cfg.batch_size
+        key = (random_actions, learn)
+        if key in graphs:
+            if learn and t_learn is None:
+                torch.cuda.synchronize(dev)
+                t_learn, learn_from = time.perf_counter(), step
+            graphs[key].replay()
+            if learn:
+                agent.updates += cfg.updates_per_step
+        elif warm.get(key, 0) < warmup_iters:
+            # a few eager iterations first (they are real training steps): allocator pools, autograd and
+            # optimiser state must exist before capture
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                iteration(random_actions, learn)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            warm[key] = warm.get(key, 0) + 1
+        else:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(dev)
+            upd = agent.updates
+            with torch.cuda.graph(g):
+                iteration(random_actions, learn)
+            agent.updates = upd            # capture runs no kernel
+            graphs[key] = g
+            continue
+        step += 1
+        buffer.advance_host(n)
+        if first_food_s is None and (step % poll_every == 0 or step == total_vector_steps):
+            f = int(first_t.item())                      # the only host read of the loop
+            if f >= 0:
+                first_food_s, first_food_step = time.perf_counter() - t0, f
+                if stop_at_first_food:
+                    break
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    finished = int(fin_cnt.item())
+    return {"wall_s": wall, "vector_steps": step, "env_steps": step * n, "updates": agent.updates,
+            "first_food_wall_s": first_food_s, "first_food_vector_step": first_food_step,
+            "episodes": finished, "mean_return": float(fin_ret.item()) / max(finished, 1),
+            "graphs": len(graphs),
+            "learn_ms_per_vector_step": None if t_learn is None or step <= learn_from else
+            (t0 + wall - t_learn) * 1e3 / (step - learn_from),
             **{k: float(v) for k, v in last.items()}}
