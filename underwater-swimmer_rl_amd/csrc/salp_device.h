@@ -120,23 +120,47 @@ __device__ __forceinline__ bool is_none(double fx) { return fx != fx; }
 #define SALP_2PI 6.283185307179586
 #define SALP_PIO2 1.5707963267948966
 
-template <int FMAX>
-struct Env {
+// Everything of one env except the food positions.
+struct EnvCore {
   double x, y, vx, vy, th, om, noz, water, epret;
-  double fx[FMAX], fy[FMAX];
   uint32_t packed;
   int ssf, fc, eplen;
   uint32_t rng;
 };
-
+// One env with its food positions in registers (all indexing static).  The multi-food rollout kernel
+// keeps the foods in LDS instead (salp_food_lds.h) and only an EnvCore in registers.
 template <int FMAX>
-__device__ __forceinline__ void load_env(Env<FMAX>& e, const DevState& S, const DevParams& P, int64_t i) {
+struct Env : EnvCore {
+  double fx[FMAX], fy[FMAX];
+};
+
+__device__ __forceinline__ void load_core(EnvCore& e, const DevState& S, const DevParams& P, int64_t i) {
   const int64_t p = P.pitch;
   e.x = S.f[SF_X * p + i]; e.y = S.f[SF_Y * p + i];
   e.vx = S.f[SF_VX * p + i]; e.vy = S.f[SF_VY * p + i];
   e.th = S.f[SF_TH * p + i]; e.om = S.f[SF_OM * p + i];
   e.noz = S.f[SF_NOZ * p + i]; e.water = S.f[SF_WATER * p + i];
   e.epret = S.f[SF_EPRET * p + i];
+  e.packed = (uint32_t)S.i[SI_PACKED * p + i];
+  e.ssf = S.i[SI_SSF * p + i]; e.fc = S.i[SI_FC * p + i];
+  e.rng = (uint32_t)S.i[SI_RNG * p + i]; e.eplen = S.i[SI_EPLEN * p + i];
+}
+__device__ __forceinline__ void store_core(const EnvCore& e, const DevState& S, const DevParams& P, int64_t i) {
+  const int64_t p = P.pitch;
+  S.f[SF_X * p + i] = e.x; S.f[SF_Y * p + i] = e.y;
+  S.f[SF_VX * p + i] = e.vx; S.f[SF_VY * p + i] = e.vy;
+  S.f[SF_TH * p + i] = e.th; S.f[SF_OM * p + i] = e.om;
+  S.f[SF_NOZ * p + i] = e.noz; S.f[SF_WATER * p + i] = e.water;
+  S.f[SF_EPRET * p + i] = e.epret;
+  S.i[SI_PACKED * p + i] = (int32_t)e.packed;
+  S.i[SI_SSF * p + i] = e.ssf; S.i[SI_FC * p + i] = e.fc;
+  S.i[SI_RNG * p + i] = (int32_t)e.rng; S.i[SI_EPLEN * p + i] = e.eplen;
+}
+
+template <int FMAX>
+__device__ __forceinline__ void load_env(Env<FMAX>& e, const DevState& S, const DevParams& P, int64_t i) {
+  const int64_t p = P.pitch;
+  load_core(e, S, P, i);
 #pragma unroll
   for (int k = 0; k < FMAX; ++k) {
     if (k < P.F) {
@@ -146,19 +170,12 @@ __device__ __forceinline__ void load_env(Env<FMAX>& e, const DevState& S, const 
       e.fx[k] = __builtin_nan(""); e.fy[k] = __builtin_nan("");
     }
   }
-  e.packed = (uint32_t)S.i[SI_PACKED * p + i];
-  e.ssf = S.i[SI_SSF * p + i]; e.fc = S.i[SI_FC * p + i];
-  e.rng = (uint32_t)S.i[SI_RNG * p + i]; e.eplen = S.i[SI_EPLEN * p + i];
 }
 
 template <int FMAX>
 __device__ __forceinline__ void store_env(const Env<FMAX>& e, const DevState& S, const DevParams& P, int64_t i) {
   const int64_t p = P.pitch;
-  S.f[SF_X * p + i] = e.x; S.f[SF_Y * p + i] = e.y;
-  S.f[SF_VX * p + i] = e.vx; S.f[SF_VY * p + i] = e.vy;
-  S.f[SF_TH * p + i] = e.th; S.f[SF_OM * p + i] = e.om;
-  S.f[SF_NOZ * p + i] = e.noz; S.f[SF_WATER * p + i] = e.water;
-  S.f[SF_EPRET * p + i] = e.epret;
+  store_core(e, S, P, i);
 #pragma unroll
   for (int k = 0; k < FMAX; ++k) {
     if (k < P.F) {
@@ -166,21 +183,17 @@ __device__ __forceinline__ void store_env(const Env<FMAX>& e, const DevState& S,
       S.f[(SF_FOOD0 + P.F + k) * p + i] = e.fy[k];
     }
   }
-  S.i[SI_PACKED * p + i] = (int32_t)e.packed;
-  S.i[SI_SSF * p + i] = e.ssf; S.i[SI_FC * p + i] = e.fc;
-  S.i[SI_RNG * p + i] = (int32_t)e.rng; S.i[SI_EPLEN * p + i] = e.eplen;
 }
 
 // One Philox block of this env's draw stream (include/salp_vec.h "Randomness").
-template <int FMAX>
-__device__ __forceinline__ U4 next_block(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
+__device__ __forceinline__ U4 next_block(EnvCore& e, const DevParams& P, uint64_t genv) {
   U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), e.rng, 0u, P.seed_lo, P.seed_hi);
   e.rng += 1u;
   return w;
 }
 
 template <int FMAX, bool STD>
-__device__ __forceinline__ void draw_xy(Env<FMAX>& e, const DevParams& P, uint64_t genv, double& x, double& y) {
+__device__ __forceinline__ void draw_xy(EnvCore& e, const DevParams& P, uint64_t genv, double& x, double& y) {
   const U4 w = next_block(e, P, genv);
   x = CV(food_xlo) + CV(food_xspan) * u53(w.x, w.y);
   y = CV(food_ylo) + CV(food_yspan) * u53(w.z, w.w);
@@ -292,8 +305,8 @@ __device__ __forceinline__ void place_food(Env<FMAX>& e, const DevParams& P, uin
 
 // legacy:95-117 reset + snake:133-149 (pose, breathing, counters, episode food count); the food
 // itself is placed by place_food(e, ..., todo = return value, limit = 100).
-template <int FMAX, bool STD>
-__device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
+template <bool STD>
+__device__ __forceinline__ int reset_core(EnvCore& e, const DevParams& P, uint64_t genv) {
   e.x = CV(half_W); e.y = CV(half_H); e.vx = 0.0; e.vy = 0.0; e.th = 0.0; e.om = 0.0;
   e.noz = 0.0; e.water = 0.0; e.epret = 0.0;
   e.packed = pack_breath(0, 0, bw_dur(e.packed), 7);
@@ -305,6 +318,11 @@ __device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint
     nf = 1 + (int)(((uint64_t)w.x * (uint64_t)n) >> 32);
     if (nf > P.F) nf = P.F;
   }
+  return nf;
+}
+template <int FMAX, bool STD>
+__device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
+  const int nf = reset_core<STD>(e, P, genv);
 #pragma unroll
   for (int k = 0; k < FMAX; ++k) { e.fx[k] = __builtin_nan(""); e.fy[k] = __builtin_nan(""); }
   return nf;
@@ -315,7 +333,7 @@ __device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint
 // sincos(phi) serves all three: the side angle is a quarter turn plus the (exactly recovered)
 // rounding error of the addition, the jitter angle a rotation by |D| <= 0.025 (short series).
 template <int FMAX, bool STD>
-__device__ __forceinline__ void apply_jet_thrust(Env<FMAX>& e, const DevParams& P, uint64_t genv, double r) {
+__device__ __forceinline__ void apply_jet_thrust(EnvCore& e, const DevParams& P, uint64_t genv, double r) {
   const double T = (CV(thrust_force) * e.water) * 0.4;
   const double phi = e.th - e.noz;
   double s, c;
@@ -443,8 +461,9 @@ struct StepOut {
 // The respawn of a collected food (snake:179-180) is left to the caller — place_food(todo = 1,
 // limit = 50) when o.collected && P.respawn, BEFORE any autoreset so the draw order of the
 // reference is kept.  (The all-collected termination test only applies when !P.respawn.)
-template <int FMAX, bool FORCED, bool STD>
-__device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, uint64_t genv, float a0, float a1) {
+// legacy:119-156 up to and including the wall bounce; returns r = max(ellipse_a, ellipse_b) of this step.
+template <bool FORCED, bool STD>
+__device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint64_t genv, float a0, float a1) {
   int phase = bw_phase(e.packed), timer = bw_timer(e.packed), dur = bw_dur(e.packed);
   // legacy:121-135
   double nd;
@@ -510,7 +529,7 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
 #ifdef SALP_EXP_NO_THRUST      // experiment build (profiles/ab_bench.py): price of the thrust block
   thrust = false;
 #endif
-  if (thrust) apply_jet_thrust<FMAX, STD>(e, P, genv, r);
+  if (thrust) apply_jet_thrust<1, STD>(e, P, genv, r);
   e.water = water_next;
   e.packed = pack_breath(phase, timer, dur, hold);
   // legacy:316-352 _update_physics
@@ -535,6 +554,30 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
     if (e.y < m) { e.y = m; e.vy = fabs(e.vy) * 0.4; e.om = e.om * 0.7; }
     else if (e.y > hy) { e.y = hy; e.vy = -fabs(e.vy) * 0.4; e.om = e.om * 0.7; }
   }
+  return r;
+}
+
+// snake:171-189 counters and termination, given the step's reward so far (everything but the counters)
+// and whether any food is still alive (only read when !P.respawn).
+__device__ __forceinline__ void step_tail(EnvCore& e, const DevParams& P, StepOut& o, double rew, bool any_alive) {
+  e.ssf += 1;
+  if (o.collected) {
+    e.fc += 1;
+    e.ssf = 0;
+    o.rel_valid = false;  // the food set changed after the reward was computed
+  }
+  o.terminated = false; o.truncated = false;
+  if (o.collision) o.terminated = true;
+  else if (e.ssf > P.max_steps_wo_food) o.truncated = true;
+  else if (!P.respawn && !any_alive) o.terminated = true;
+  e.eplen += 1;
+  e.epret += rew;
+  o.reward = (float)rew;
+}
+
+template <int FMAX, bool FORCED, bool STD>
+__device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, uint64_t genv, float a0, float a1) {
+  const double r = step_head<FORCED, STD>(e, P, genv, a0, a1);
   StepOut o;
   o.rmax = r;
   // snake:204-217 _check_food_collection (first live food inside the capture radius)
@@ -578,25 +621,12 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
     }
   }
   rew += P.time_penalty;
-  // snake:171-189
-  e.ssf += 1;
-  if (o.collected) {
-    e.fc += 1;
-    e.ssf = 0;
-    o.rel_valid = false;  // the food set changed after the reward was computed
-  }
-  o.terminated = false; o.truncated = false;
-  if (o.collision) o.terminated = true;
-  else if (e.ssf > P.max_steps_wo_food) o.truncated = true;
-  else if (!P.respawn) {
-    bool any = false;
+  bool any_alive = false;
+  if (!P.respawn) {
 #pragma unroll
-    for (int k = 0; k < FMAX; ++k) any = any || !is_none(e.fx[k]);
-    if (!any) o.terminated = true;
+    for (int k = 0; k < FMAX; ++k) any_alive = any_alive || !is_none(e.fx[k]);
   }
-  e.eplen += 1;
-  e.epret += rew;
-  o.reward = (float)rew;
+  step_tail(e, P, o, rew, any_alive);
   return o;
 }
 

@@ -1,0 +1,298 @@
+// salp_food_lds.h — the multi-food (num_food_items > 1) side of the rollout kernel, with the food
+// positions of an env in LDS instead of registers.
+//
+// With 12 foods the register form (Env<12>: 48 VGPRs of positions, three unrolled 12-way distance passes
+// per step, a 3 x 12 select network for the K nearest) ran at 256 VGPRs with ~30 VGPR and ~150 SGPR spills
+// and ~1400 instructions per wavefront-step.  Here an env keeps only its EnvCore in registers; slot k of
+// lane l lives at col[k * 64] (16 B per slot, lane-contiguous: conflict-free ds_read_b128 / ds_write_b128
+// for any per-lane k), and ONE rolled pass per step over the slots serves, from one fp64 squared distance
+// per food, the capture test (snake:204-217), the live count and distance sum (snake:414-420) and the
+// K nearest (snake:382, stable by slot) through a sorted insertion on the exact fp64 keys.
+// The arithmetic on each food is the reference's, in its order: nothing here is approximate.
+#pragma once
+#include "salp_device.h"
+
+namespace salp {
+
+constexpr int kFoodLanes = 64;
+
+struct FoodLds {
+  double2* col;   // this lane's column of the wavefront's [FMAX][64] block
+  __device__ __forceinline__ void get(int k, double& x, double& y) const {
+    const double2 v = col[k * kFoodLanes];
+    x = v.x; y = v.y;
+  }
+  __device__ __forceinline__ void set(int k, double x, double y) const { col[k * kFoodLanes] = make_double2(x, y); }
+  __device__ __forceinline__ void clear(int k) const { set(k, __builtin_nan(""), __builtin_nan("")); }
+};
+
+// Result of one pass over the slots.
+template <int KMAX>
+struct FoodScan {
+  double t[KMAX];    // squared distances of the K nearest live foods, ascending (+inf: none)
+  int idx[KMAX];     // their slots (-1: none); equal distances keep slot order
+  float bx[KMAX], by[KMAX], bd[KMAX];   // offsets and distance of those foods in fp32 (filled by resolve())
+  float dsum;        // sum of distances over ALL live foods
+  int cnt;           // live foods
+};
+
+// One pass over slots 0..F-1 around (x, y).  CAPTURE: also the reference's capture test with radius^2 =
+// cr2 — the first slot inside wins, is reported in hit_k and is treated as already gone by everything
+// else in the pass (the reward's nearest food and the observation are taken after it is cleared,
+// snake:171-189, 301).
+template <int KMAX, bool CAPTURE>
+__device__ __forceinline__ void scan_foods(const FoodLds& f, int F, double x, double y, double cr2, FoodScan<KMAX>& q,
+                                           bool& collected, int& hit_k) {
+  const double inf = __builtin_inf();
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) { q.t[s] = inf; q.idx[s] = -1; }
+  float dsum = 0.f;
+  int cnt = 0;
+  collected = false;
+  hit_k = 0;
+#pragma unroll 2
+  for (int k = 0; k < F; ++k) {
+    double fx, fy;
+    f.get(k, fx, fy);
+    const double dx = fx - x, dy = fy - y;
+    const double d2 = dx * dx + dy * dy;
+    bool live = !is_none(fx);
+    if (CAPTURE) {
+      const bool hit = !collected && (d2 < cr2);   // NaN (empty slot) never hits
+      collected = collected || hit;
+      hit_k = hit ? k : hit_k;
+      live = live && !hit;
+    }
+    cnt += live ? 1 : 0;
+    dsum += live ? __builtin_amdgcn_sqrtf((float)d2) : 0.f;
+    const double v = live ? d2 : inf;
+    // sorted insertion as a chain of compare-exchanges (v_min_f64 / v_max_f64 + two selects for the slot):
+    // the newcomer only moves ahead of strictly larger keys, so equal distances keep their slot order
+    double cv = v;
+    int ck = k;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+      const bool lt = cv < q.t[s];
+      const double lo = __builtin_fmin(cv, q.t[s]), hi = __builtin_fmax(cv, q.t[s]);
+      const int ilo = lt ? ck : q.idx[s], ihi = lt ? q.idx[s] : ck;
+      q.t[s] = lo; q.idx[s] = ilo;
+      cv = hi; ck = ihi;
+    }
+  }
+  q.dsum = dsum;
+  q.cnt = cnt;
+}
+
+// fp32 geometry of the first K selected foods (what the reward and the observation consume).
+template <int KMAX>
+__device__ __forceinline__ void resolve(const FoodLds& f, int K, double x, double y, FoodScan<KMAX>& q) {
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    q.bx[s] = 0.f; q.by[s] = 0.f; q.bd[s] = 0.f;
+    if (s < K) {
+      double fx, fy;
+      f.get(q.idx[s] < 0 ? 0 : q.idx[s], fx, fy);
+      const bool found = q.idx[s] >= 0;
+      q.bx[s] = found ? (float)(fx - x) : 0.f;
+      q.by[s] = found ? (float)(fy - y) : 0.f;
+      q.bd[s] = found ? __builtin_amdgcn_sqrtf((float)q.t[s]) : 0.f;
+    }
+  }
+}
+
+// One reference step of a multi-food env (the LDS counterpart of step_env<FMAX>): same order of
+// operations, the food loop being one scan.  Leaves the selection of the post-step food set in q.
+template <int KMAX, bool FORCED, bool STD>
+__device__ __forceinline__ StepOut step_env_lds(EnvCore& e, const FoodLds& f, const DevParams& P, uint64_t genv, float a0, float a1,
+                                                int K, FoodScan<KMAX>& q) {
+  const double r = step_head<FORCED, STD>(e, P, genv, a0, a1);
+  StepOut o;
+  o.rmax = r;
+  const double cr = r + CV(food_radius);
+  int hit_k;
+  scan_foods<KMAX, true>(f, P.F, e.x, e.y, cr * cr, q, o.collected, hit_k);
+  if (__any(o.collected)) {
+    if (o.collected) f.clear(hit_k);
+  }
+  resolve<KMAX>(f, K > 0 ? K : 1, e.x, e.y, q);   // the reward needs the nearest even when K = 0
+  o.collision = (e.x - r <= CV(margin)) || (e.x + r >= CV(wall_hi_x)) || (e.y - r <= CV(margin)) || (e.y + r >= CV(wall_hi_y));
+  double rew = 0.0;
+  if (o.collected) {
+    rew += P.food_reward;
+    if (P.efficiency_bonus > 0) rew += P.efficiency_bonus * (double)(P.max_steps_wo_food - e.ssf);
+  }
+  if (o.collision) rew += P.collision_penalty;
+  o.rel = relative_heading(q.by[0], q.bx[0], (float)e.th);
+  o.rel_valid = q.idx[0] >= 0;
+  if (P.prox_w > 0) {
+    const double al = P.prox_w * (double)cos_wrapped(o.rel);
+    rew += o.rel_valid ? al : 0.0;
+  }
+  rew += P.time_penalty;
+  step_tail(e, P, o, rew, q.cnt > 0);
+  return o;
+}
+
+// The observation row from a scan of the CURRENT food set around the CURRENT pose.
+template <int KMAX, bool STD>
+__device__ __forceinline__ void observe_lds(const EnvCore& e, const DevParams& P, double rmax, int K, const FoodScan<KMAX>& q,
+                                            bool have_rel, float rel0, float (&o)[12 + 4 * KMAX]) {
+  o[0] = (float)e.x * (float)CV(inv_W);
+  o[1] = (float)e.y * (float)CV(inv_H);
+  o[2] = (float)e.vx * 0.2f;
+  o[3] = (float)e.vy * 0.2f;
+  o[4] = (float)e.th * (float)CV(inv_pi);
+  o[5] = (float)e.om * 10.0f;
+  o[6] = (float)rmax * (float)CV(inv_R);
+  o[7] = (float)bw_phase(e.packed) * 0.5f;
+  o[8] = (float)e.water;
+  o[9] = (float)e.noz * (float)CV(inv_max_nozzle);
+  const float th = (float)e.th;
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    float v0 = 0.f, v1 = 0.f, v2 = 1.f, v3 = 0.f;   // padding for an empty slot (snake:412)
+    if (s < K) {
+      const bool found = q.idx[s] >= 0;
+      float rel;
+      if (s == 0 && __all(have_rel)) rel = rel0;    // wave-uniform: skips the second atan2
+      else {
+        rel = relative_heading(q.by[s], q.bx[s], th);
+        if (s == 0) rel = have_rel ? rel0 : rel;
+      }
+      v0 = found ? q.bx[s] * (float)CV(inv_W) : 0.f;
+      v1 = found ? q.by[s] * (float)CV(inv_H) : 0.f;
+      v2 = found ? q.bd[s] * CV(inv_diag) : 1.f;
+      v3 = found ? rel * 0.318309886183791f : 0.f;
+    }
+    o[10 + 4 * s + 0] = v0; o[10 + 4 * s + 1] = v1; o[10 + 4 * s + 2] = v2; o[10 + 4 * s + 3] = v3;
+  }
+  const float fcnt = (float)q.cnt;
+  const float s0 = fminf(fcnt * 0.1f, 1.0f);
+  const float s1 = (q.cnt > 0) ? (q.dsum * __builtin_amdgcn_rcpf(fcnt)) * CV(inv_diag) : 1.0f;
+  if (KMAX == 3) {
+    o[22] = s0; o[23] = s1;
+  } else {
+#pragma unroll
+    for (int s = 0; s <= KMAX; ++s) if (s == K) { o[10 + 4 * s] = s0; o[11 + 4 * s] = s1; }
+  }
+}
+
+// place_food (salp_device.h) on LDS slots: the same rejection sampler, draw for draw.
+template <bool STD>
+__device__ __forceinline__ void place_food_lds(EnvCore& e, const FoodLds& f, const DevParams& P, uint64_t genv, int todo, int limit) {
+  int attempts = 0;
+#pragma unroll 1
+  while (__any(todo > 0)) {
+    if (todo > 0) {
+      double x, y;
+      draw_xy<1, STD>(e, P, genv, x, y);
+      bool valid = true;
+      {
+        const double dx = x - e.x, dy = y - e.y;
+        if (dx * dx + dy * dy < CV(min_food_dist2)) valid = false;
+      }
+      int first_empty = -1;
+#pragma unroll 1
+      for (int k = 0; k < P.F; ++k) {
+        double fx, fy;
+        f.get(k, fx, fy);
+        const double dx = x - fx, dy = y - fy;
+        if (dx * dx + dy * dy < CV(min_food_dist2)) valid = false;   // NaN (empty) slots never reject
+        if (first_empty < 0 && is_none(fx)) first_empty = k;
+      }
+      if (valid || attempts >= limit) {
+        if (first_empty >= 0) f.set(first_empty, x, y);
+        todo -= 1;
+        attempts = 0;
+      } else {
+        attempts += 1;
+      }
+    }
+  }
+}
+
+// ---- wavefront-cooperative placement ---------------------------------------------------------------------
+// place_food_lds run by 64 lanes for the one or two envs of a wavefront that need food costs the whole
+// wavefront a serial rejection loop: an autoreset with 12 foods is ~18 draws, each a Philox block plus 12
+// distance tests, ~5000 instructions with 63 lanes idle, and with ~1/800 resets per env-step some lane of
+// a wavefront resets on ~8 % of the steps (measured: 37 % of the sac_gail kernel time).
+// Here the 64 lanes work for one env at a time: lane l draws candidate number (consumed + l) of THAT env's
+// stream, all candidates are tested against the robot and the env's live foods at once (broadcast LDS
+// reads), and the sequential acceptance rule of the reference — first valid draw, or the draw after
+// `limit` consecutive rejections — becomes a ballot / find-first per accepted food, with the later
+// candidates re-tested against each newly accepted one.  The draws taken, their order and the number
+// consumed from the env's stream are exactly those of place_food_lds.
+// value of `v` in lane `src` (src wave-uniform): two v_readlane instead of two LDS permutes
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <int FMAX, bool STD>
+__device__ __forceinline__ void place_food_coop(EnvCore& e, double2* wave_block, int lane, const DevParams& P, uint64_t genv,
+                                                int todo, int limit) {
+  unsigned long long need = __ballot(todo > 0);
+  const double min2 = CV(min_food_dist2);
+  while (need) {                                   // wave-uniform: one env at a time
+    const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)need) - 1);
+    need &= need - 1;
+    const uint32_t g_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)genv, L);
+    const uint32_t g_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(genv >> 32), L);
+    const uint32_t rng0 = (uint32_t)__builtin_amdgcn_readlane((int)e.rng, L);
+    const double rx = bcast_lane(e.x, L), ry = bcast_lane(e.y, L);
+    int todo_l = __builtin_amdgcn_readlane(todo, L);
+    const int limit_l = __builtin_amdgcn_readlane(limit, L);
+    const double2* colL = wave_block + L;          // slot k of env L at colL[k * 64]
+    // the env's foods, once: lane k holds slot k (one parallel read); empty slots as a scalar bit mask
+    const double2 mine = colL[(lane < P.F ? lane : 0) * kFoodLanes];
+    unsigned long long empty = __ballot(lane < P.F && is_none(mine.x));
+    uint32_t consumed = 0;                         // draws of env L's stream used so far
+    int attempts = 0;
+    while (todo_l > 0) {
+      // 64 candidates: draw number consumed + lane
+      const U4 w = philox4x32_10(g_lo, g_hi, rng0 + consumed + (uint32_t)lane, 0u, P.seed_lo, P.seed_hi);
+      const double x = CV(food_xlo) + CV(food_xspan) * u53(w.x, w.y);
+      const double y = CV(food_ylo) + CV(food_yspan) * u53(w.z, w.w);
+      bool ok;
+      {
+        const double dx = x - rx, dy = y - ry;
+        ok = !(dx * dx + dy * dy < min2);
+      }
+#pragma unroll
+      for (int k = 0; k < FMAX; ++k) {
+        if (k < P.F) {                             // wave-uniform
+          const double2 fv = colL[k * kFoodLanes]; // same address in every lane: LDS broadcast
+          const double dx = x - fv.x, dy = y - fv.y;
+          ok = ok && !(dx * dx + dy * dy < min2);  // NaN (empty) slots never reject
+        }
+      }
+      int j = 0;                                   // first candidate of this batch not yet judged
+      while (todo_l > 0 && j < kFoodLanes) {
+        const unsigned long long okm = __ballot(ok) & (~0ull << j);
+        const int first_ok = okm ? (__ffsll((long long)okm) - 1) : kFoodLanes;
+        const int forced = j + (limit_l - attempts);          // accepted whatever it is
+        const int a = __builtin_amdgcn_readfirstlane(first_ok < forced ? first_ok : forced);
+        if (a >= kFoodLanes) { attempts += kFoodLanes - j; j = kFoodLanes; break; }
+        const double ax = bcast_lane(x, a), ay = bcast_lane(y, a);
+        if (empty) {                               // first empty slot (snake:120, 261-264)
+          const int slot = __ffsll((long long)empty) - 1;
+          empty &= empty - 1;
+          if (lane == 0) wave_block[slot * kFoodLanes + L] = make_double2(ax, ay);
+        }
+        {
+          const double dx = x - ax, dy = y - ay;
+          ok = ok && !(dx * dx + dy * dy < min2);
+        }
+        todo_l -= 1;
+        attempts = 0;
+        j = a + 1;
+      }
+      consumed += (uint32_t)j;
+    }
+    if (lane == L) e.rng = rng0 + consumed;
+  }
+}
+
+}  // namespace salp

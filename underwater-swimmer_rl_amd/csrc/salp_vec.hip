@@ -23,6 +23,7 @@
 
 #include "../../include/salp_vec.h"
 #include "salp_device.h"
+#include "salp_food_lds.h"
 
 using namespace salp;
 
@@ -70,10 +71,17 @@ struct IOPtrs {
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
 template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end) {
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 12 ? 2 : 1)))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end) {
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
   constexpr int PITCH = 4 * QMAX + 4;     // LDS row pitch in floats (pad 16 B: conflict-free b128 writes)
   __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * kWave * PITCH];
+#ifdef SALP_EXP_REG_FOOD      // experiment build: multi-food envs with the foods in registers (the round-1 form)
+  constexpr bool LDSF = false;
+#else
+  // multi-food envs keep their food positions in LDS (salp_food_lds.h); one food stays in registers
+  constexpr bool LDSF = FMAX > 1;
+#endif
+  __shared__ __attribute__((aligned(16))) double2 food_lds[LDSF ? (kBlock / kWave) * FMAX * kWave : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -107,8 +115,17 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
   if (tid < 16) blk_stats[tid] = 0ull;
   __syncthreads();
 
-  Env<FMAX> e;
-  load_env(e, S, P, envc);
+  using EnvT = std::conditional_t<LDSF, EnvCore, Env<FMAX>>;
+  EnvT e;
+  const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
+  FoodScan<KMAX> fq;          // LDSF: nearest-K selection of the current food set around the current pose
+  if constexpr (LDSF) {
+    load_core(e, S, P, envc);
+    for (int k = 0; k < P.F; ++k)
+      food.set(k, S.f[(SF_FOOD0 + k) * P.pitch + envc], S.f[(SF_FOOD0 + P.F + k) * P.pitch + envc]);
+  } else {
+    load_env(e, S, P, envc);
+  }
 
   double st_reward = 0.0;   // the one per-step statistic
 
@@ -161,7 +178,9 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
     StepOut o; o.rmax = 30.0; o.reward = c0; o.rel = c1; o.rel_valid = true;
     o.terminated = o.truncated = o.collision = o.collected = false;
 #else
-    const StepOut o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
+    StepOut o;
+    if constexpr (LDSF) o = step_env_lds<KMAX, FORCED, STD>(e, food, P, genv, c0, c1, K, fq);
+    else o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
 #endif
     const bool done = o.terminated || o.truncated;
     double rmax = o.rmax;
@@ -188,7 +207,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
 
     // rare events: respawn of a collected food (snake:179-180), then same-step autoreset
     int todo = (o.collected && P.respawn) ? 1 : 0;
+#ifdef SALP_EXP_NO_RARE   // experiment build: price of the respawn / autoreset region (results are wrong)
+    if (false) {
+#else
     if (__any(o.collected || done)) {
+#endif
       int limit = 50;
       if (active && io.stats) {
         if (o.collected) atomicAdd(&blk_stats[ST_FOOD], 1ull);
@@ -205,25 +228,57 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
         if (pass == 1 && done) {
           if (!FULL && io.final_obs && active) {
             float fo[12 + 4 * KMAX];
-            observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, fo);
+            if constexpr (LDSF) {   // the terminal observation sees the respawned food (pass 0)
+              bool c_; int h_;
+              scan_foods<KMAX, false>(food, P.F, e.x, e.y, 0.0, fq, c_, h_);
+              resolve<KMAX>(food, K, e.x, e.y, fq);
+              observe_lds<KMAX, STD>(e, P, rmax, K, fq, false, 0.f, fo);
+            } else {
+              observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, fo);
+            }
             float4* dst = reinterpret_cast<float4*>(io.final_obs + (rowbase + env) * OD);
 #pragma unroll
             for (int q = 0; q < QMAX; ++q)
               if (q < Q) dst[q] = make_float4(fo[4 * q], fo[4 * q + 1], fo[4 * q + 2], fo[4 * q + 3]);
           }
-          todo = reset_pose<FMAX, STD>(e, P, genv);
+          if constexpr (LDSF) {
+            todo = reset_core<STD>(e, P, genv);
+            for (int k = 0; k < P.F; ++k) food.clear(k);
+          } else {
+            todo = reset_pose<FMAX, STD>(e, P, genv);
+          }
           limit = 100;
           rmax = CV(R);
           have_rel = false;
         }
-        place_food<FMAX, STD>(e, P, genv, todo, limit);
+#ifdef SALP_EXP_SERIAL_PLACE
+        if constexpr (LDSF) place_food_lds<STD>(e, food, P, genv, todo, limit);
+#else
+        if constexpr (LDSF) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          place_food_coop<FMAX, STD>(e, food_lds + wave * FMAX * kWave, lane, P, genv, todo, limit);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#endif
+        else place_food<FMAX, STD>(e, P, genv, todo, limit);
         todo = 0;
+      }
+      if constexpr (LDSF) {   // the food set (or the pose) changed: select again for the observation
+        bool c_; int h_;
+        scan_foods<KMAX, false>(food, P.F, e.x, e.y, 0.0, fq, c_, h_);
+        resolve<KMAX>(food, K, e.x, e.y, fq);
+        have_rel = false;
       }
     }
 
     if (FULL || io.obs) {
       float ob[12 + 4 * KMAX];
-      observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
+      if constexpr (LDSF) observe_lds<KMAX, STD>(e, P, rmax, K, fq, have_rel, o.rel, ob);
+      else observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
 #ifdef SALP_EXP_DIRECT_STORE   // experiment: per-lane 96-B rows straight from registers (no LDS transpose)
       if (active) {
         float4* drow = reinterpret_cast<float4*>(io.obs + (rowbase + env) * OD);
@@ -270,7 +325,19 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : 2))) void
 #endif
   }
 
-  if (rows > 0 && active) store_env(e, S, P, env);
+  if (rows > 0 && active) {
+    if constexpr (LDSF) {
+      store_core(e, S, P, env);
+      for (int k = 0; k < P.F; ++k) {
+        double fx, fy;
+        food.get(k, fx, fy);
+        S.f[(SF_FOOD0 + k) * P.pitch + env] = fx;
+        S.f[(SF_FOOD0 + P.F + k) * P.pitch + env] = fy;
+      }
+    } else {
+      store_env(e, S, P, env);
+    }
+  }
 
   if (io.stats) {
     // reward sum: wavefront shuffles, then one LDS atomic per wavefront; env-step count likewise.
