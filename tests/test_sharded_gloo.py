@@ -102,3 +102,38 @@ def test_two_rank_sharding_equals_single_process(tmp_path):
     g_all = r0["g_all"]                                                      # [G, H, n_local, D]
     assert g_all.shape == (2, 10, 32, cfg.obs_dim)
     assert np.array_equal(np.concatenate([g_all[0], g_all[1]], axis=1), out["obs"])
+
+
+def _sac_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from underwater_swimmer_rl_amd.sac import SAC, SACConfig
+        torch.manual_seed(100 + rank)                       # replicas start from DIFFERENT weights ...
+        cfg = SACConfig(hidden_sizes=(32, 32), batch_size=64, alpha=None)
+        agent = SAC(24, 1, cfg, device="cpu", data_parallel=True)
+        flat = lambda: torch.cat([p.detach().reshape(-1) for p in [*agent.actor.parameters(), *agent.critic.parameters(),
+                                                                    *agent.critic_target.parameters(), agent.log_alpha]])
+        start = flat().clone()
+        g = torch.Generator().manual_seed(7 + rank)         # ... and learn from DIFFERENT data
+        for _ in range(6):
+            batch = (torch.randn(64, 24, generator=g), torch.rand(64, 1, generator=g) * 2 - 1, torch.randn(64, generator=g),
+                     torch.randn(64, 24, generator=g), (torch.rand(64, generator=g) > 0.9).float())
+            agent.update(batch)
+        torch.save({"start": start, "end": flat(), "updates": agent.updates}, os.path.join(tmp, f"sac{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_sac_replicas_stay_identical(tmp_path):
+    """SAC(data_parallel=True): broadcast at construction, one gradient all-reduce (mean) per backward."""
+    port = _free_port()
+    mp.spawn(_sac_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(tmp_path, "sac0.pt"), weights_only=True)
+    b = torch.load(os.path.join(tmp_path, "sac1.pt"), weights_only=True)
+    assert torch.equal(a["start"], b["start"])                 # rank 0's weights everywhere
+    assert not torch.equal(a["start"], a["end"])               # learning happened
+    assert torch.equal(a["end"], b["end"])                     # and the replicas never diverged
+    assert a["updates"] == b["updates"] == 6

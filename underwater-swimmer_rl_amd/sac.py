@@ -177,8 +177,14 @@ AGENT_PRESETS: Dict[str, dict] = {
 
 class SAC:
     def __init__(self, obs_dim, act_dim, cfg: SACConfig = SACConfig(), device="cuda", act_low=None, act_high=None,
-                 learn_alpha: Optional[bool] = None, seed: Optional[int] = None):
+                 learn_alpha: Optional[bool] = None, seed: Optional[int] = None, process_group=None,
+                 data_parallel: bool = False):
+        """`data_parallel=True` (needs an initialised `torch.distributed`, backend "nccl" = RCCL on GPUs):
+        one learner replica per rank, each fed by its own env shard and replay buffer; parameters are
+        broadcast from rank 0 at construction and every backward is followed by one flat all-reduce
+        (mean) of that network's gradients, so the replicas stay bit-identical."""
         self.cfg, self.device = cfg, torch.device(device)
+        self.pg, self.data_parallel = process_group, bool(data_parallel)
         if seed is not None:
             torch.manual_seed(seed)
         self.actor = Actor(obs_dim, act_dim, cfg.hidden_sizes, act_low, act_high).to(self.device)
@@ -198,6 +204,35 @@ class SAC:
         self.alpha_opt = torch.optim.Adam([self.log_alpha], lr=cfg.alpha_lr, capturable=cap) if self.learn_alpha else None
         self.target_entropy = -float(act_dim) if cfg.target_entropy is None else float(cfg.target_entropy)
         self.updates = 0
+        self.world = 1
+        if self.data_parallel:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError("data_parallel=True needs torch.distributed to be initialised")
+            self.world = dist.get_world_size(self.pg)
+            src = dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
+            with torch.no_grad():
+                for t in [*self.actor.parameters(), *self.critic.parameters(), *self.critic_target.parameters(),
+                          self.log_alpha]:
+                    dist.broadcast(t, src=src, group=self.pg)
+            if seed is not None:    # same weights everywhere, different exploration noise per replica
+                torch.manual_seed(seed + 1 + dist.get_rank(self.pg))
+
+    def _average_grads(self, params):
+        """One all-reduce for the whole network (a few hundred KB: a single bucket is the right size for
+        xGMI's per-link ring), then the mean."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        grads = [p.grad for p in params if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, group=self.pg)
+        flat.div_(self.world)
+        o = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[o:o + n].view_as(g))
+            o += n
 
     @torch.no_grad()
     def act(self, obs, deterministic=False):
@@ -215,6 +250,7 @@ class SAC:
         critic_loss = 0.5 * (F.mse_loss(q1, target) + F.mse_loss(q2, target))
         self.critic_opt.zero_grad(set_to_none=True)
         critic_loss.backward()
+        self._average_grads(list(self.critic.parameters()))
         self.critic_opt.step()
 
         pa, logp = self.actor(obs)
@@ -222,12 +258,14 @@ class SAC:
         actor_loss = (alpha * logp - torch.min(pq1, pq2)).mean()
         self.actor_opt.zero_grad(set_to_none=True)
         actor_loss.backward()
+        self._average_grads(list(self.actor.parameters()))
         self.actor_opt.step()
 
         if self.learn_alpha:
             alpha_loss = -(self.log_alpha * (logp.detach() + self.target_entropy).mean())
             self.alpha_opt.zero_grad(set_to_none=True)
             alpha_loss.backward()
+            self._average_grads([self.log_alpha])
             self.alpha_opt.step()
         with torch.no_grad():  # polyak update (core/base_agent.py:63-74 soft_update)
             for p, tp in zip(self.critic.parameters(), self.critic_target.parameters()):
@@ -283,7 +321,13 @@ def train_sac(env, agent: SAC, total_vector_steps: int, buffer: Optional[DeviceR
             finished_returns += float(ep_returns[done].sum())
             finished += int(done.sum())
             ep_returns[done] = 0.0
-        if first_food_s is None and bool((info["food_collected"] > 0).any()):
+        got_food = (info["food_collected"] > 0).any()
+        if agent.world > 1 and first_food_s is None:   # every rank must take the same branch (the updates are collective)
+            import torch.distributed as dist
+            flag = got_food.to(torch.int32).reshape(1)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=agent.pg)
+            got_food = flag[0] > 0
+        if first_food_s is None and bool(got_food):
             torch.cuda.synchronize() if dev.type == "cuda" else None
             first_food_s, first_food_step = time.perf_counter() - t0, step + 1
             if stop_at_first_food:
@@ -321,6 +365,8 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
     cfg, dev = agent.cfg, agent.device
     if dev.type != "cuda":
         raise RuntimeError("train_sac_graphed needs a ROCm device")
+    if agent.world > 1:
+        raise RuntimeError("train_sac_graphed is single-process; use train_sac for data-parallel replicas")
     n = env.num_envs
     buffer = buffer or DeviceReplayBuffer(cfg.buffer_size, env.obs_dim, env.act_dim, dev)
     low = torch.as_tensor(env.single_action_space.low, device=dev)
