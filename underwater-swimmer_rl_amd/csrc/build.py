@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "salp_vec.hip")             # SalpSnakeEnv.step hot path
 SRC_ROBOT = os.path.join(HERE, "salp_robot.hip")     # HEAD Robot simulator
-DEPS = [SRC, SRC_ROBOT, os.path.join(HERE, "salp_device.h"),
+DEPS = [SRC, SRC_ROBOT, os.path.join(HERE, "salp_device.h"), os.path.join(HERE, "salp_food_lds.h"),
         os.path.join(HERE, "..", "..", "include", "salp_vec.h"),
         os.path.join(HERE, "..", "..", "include", "salp_robot.h")]
 OUT = os.path.join(HERE, "libsalp_hip.so")
