@@ -206,6 +206,14 @@ int salp_vec_get_stats(salp_vec_t* h, salp_stats_t* out);  /* synchronises the h
 int salp_vec_clear_stats(salp_vec_t* h);
 int64_t salp_vec_global_step(const salp_vec_t* h);
 
+/* The curriculum's attribute poke `env.base_num_food_items = k` (src/salp/training/continuous_trainer.py:409-411;
+ * src/salp/environments/salp_snake_env.py:36): the number of foods placed at every LATER reset of an env
+ * (snake:144-148; with random_food_count the upper bound of the draw).  0 <= k <= the num_food_items the
+ * handle was created with, which fixes the number of food slots (create with the curriculum's maximum and
+ * lower it here).  Takes effect from the next call; envs mid-episode keep their foods. */
+int salp_vec_set_base_num_food(salp_vec_t* h, int32_t k);
+int32_t salp_vec_base_num_food(const salp_vec_t* h);
+
 #ifdef __cplusplus
 }
 #endif

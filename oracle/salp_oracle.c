@@ -80,6 +80,7 @@ struct salp_oracle {
   uint64_t seed;
   int64_t base;
   int64_t global_step;
+  int base_num_food;                 /* snake:36 base_num_food_items: foods of the NEXT episodes (<= cfg.num_food_items slots) */
   env_t* env;
 };
 
@@ -211,10 +212,11 @@ static void reset_env(const struct salp_oracle* h, int64_t i, env_t* e) {
   if (c->random_food_count) { /* snake:144-146 random.randint(1, max(1, base)) */
     uint32_t w[4];
     next_block(h, i, e, w);
-    int n = c->num_food_items > 1 ? c->num_food_items : 1;
+    int n = h->base_num_food > 1 ? h->base_num_food : 1;
     e->num_food = 1 + (int)(((uint64_t)w[0] * (uint64_t)n) >> 32);
+    if (e->num_food > c->num_food_items) e->num_food = c->num_food_items;
   } else {
-    e->num_food = c->num_food_items;
+    e->num_food = h->base_num_food;
   }
   generate_food(h, i, e);
 }
@@ -444,6 +446,7 @@ int salp_oracle_create(const salp_config_t* cfg, int64_t n, uint64_t seed, int64
   salp_oracle_t* h = (salp_oracle_t*)calloc(1, sizeof(*h));
   if (!h) return -4;
   h->cfg = *cfg; h->n = n; h->seed = seed; h->base = base; h->global_step = 0;
+  h->base_num_food = cfg->num_food_items;
   h->env = (env_t*)calloc((size_t)n, sizeof(env_t));
   if (!h->env) { free(h); return -4; }
   for (int64_t i = 0; i < n; ++i) { h->env[i].rng_counter = 0; reset_env(h, i, &h->env[i]); }
@@ -613,3 +616,11 @@ int salp_oracle_set_state(salp_oracle_t* h, const double* f64, const int32_t* i3
 }
 
 int64_t salp_oracle_global_step(const salp_oracle_t* h) { return h->global_step; }
+
+/* The reference's curriculum pokes `env.base_num_food_items = k` (continuous_trainer.py:409-411); it takes
+   effect at each env's next reset (snake:144-148). */
+int salp_oracle_set_base_num_food(salp_oracle_t* h, int k) {
+  if (!h || k < 0 || k > h->cfg.num_food_items) return -1;
+  h->base_num_food = k;
+  return 0;
+}

@@ -36,6 +36,7 @@ int salp_oracle_rollout_f64(salp_oracle_t* h, const double* act64, int32_t horiz
 int salp_oracle_get_state(salp_oracle_t* h, double* f64, int32_t* i32);
 int salp_oracle_set_state(salp_oracle_t* h, const double* f64, const int32_t* i32);
 int64_t salp_oracle_global_step(const salp_oracle_t* h);
+int salp_oracle_set_base_num_food(salp_oracle_t* h, int k);   /* snake:36 base_num_food_items, 0..num_food_items */
 #ifdef __cplusplus
 }
 #endif

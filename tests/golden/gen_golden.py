@@ -14,6 +14,7 @@ Each fixture `ref_<case>.npz` holds inputs and expected outputs only (no referen
   terminated, truncated  u8 [H, N]
   info          i32 [H, N, 3]         food_collected, steps_since_food, collision (pre-autoreset)
   end_f64 / end_i32   state snapshot after the last step
+  food_schedule (optional) i32 [M, 2]  rows (t, k): `env.base_num_food_items = k` written before step t
 Autoreset is emulated the way a VectorEnv would drive the reference: when step() reports
 terminated or truncated, reset() is called and its observation replaces the returned one.
 """
@@ -77,7 +78,21 @@ def apply_injection(r, col, f64, F):
 ESCAPES = [0]
 
 
-def run_case(name, params, actions, seed, base=0, inject=None, notes=""):
+class _Any:
+    """Stands in for the event counts of a fixture that is not being regenerated (`gen_golden.py name ...`)."""
+    def _t(self, *_):
+        return True
+    __eq__ = __ge__ = __gt__ = __le__ = __lt__ = _t
+    __hash__ = None
+
+
+ONLY = [None]
+
+
+def run_case(name, params, actions, seed, base=0, inject=None, notes="", food_schedule=None):
+    if ONLY[0] and name not in ONLY[0]:
+        import collections
+        return collections.defaultdict(_Any)
     ESCAPES[0] = 0
     cfg = pkg.load_env_config(params.pop("preset"), **params) if "preset" in params else pkg.SalpSnakeConfig(**params)
     H, n, ad = actions.shape
@@ -102,7 +117,11 @@ def run_case(name, params, actions, seed, base=0, inject=None, notes=""):
     term = np.zeros((H, n), np.uint8)
     trunc = np.zeros((H, n), np.uint8)
     info = np.zeros((H, n, 3), np.int32)
+    sched = dict(food_schedule or [])
     for t in range(H):
+        if t in sched:      # the curriculum's attribute poke (continuous_trainer.py:409-411), before step t
+            for r in envs:
+                r.env.base_num_food_items = sched[t]
         for i, r in enumerate(envs):
             pre_phase, pre_timer = r.env.breathing_phase, r.env.breathing_timer
             o, rw, te, tr, inf = r.step(actions[t, i])
@@ -129,6 +148,8 @@ def run_case(name, params, actions, seed, base=0, inject=None, notes=""):
                reward=rew, terminated=term, truncated=trunc, info=info, end_f64=end_f64, end_i32=end_i32)
     if inj_f64 is not None:
         out["inject_f64"], out["inject_i32"] = inj_f64, inj_i32
+    if food_schedule:
+        out["food_schedule"] = np.asarray(sorted(food_schedule), np.int32)     # rows (step, base_num_food_items)
     path = os.path.join(HERE, f"ref_{name}.npz")
     np.savez_compressed(path, **out)
     ev = dict(terminated=int(term.sum()), truncated=int(trunc.sum()), food=int(info[..., 0].max()),
@@ -141,7 +162,8 @@ def uniform_actions(H, n, ad, seed, lo=-1.0, hi=1.0):
     return np.random.default_rng(seed).uniform(lo, hi, size=(H, n, ad)).astype(np.float32)
 
 
-def main():
+def main(only=None):
+    ONLY[0] = only
     # --- the three BASELINE presets, 8 envs x 256 steps
     for k, preset in enumerate(("single_food", "single_food_long_horizon", "sac_gail")):
         cfg = pkg.load_env_config(preset)
@@ -231,6 +253,15 @@ def main():
     a[100, 2, 0] = np.inf
     run_case("wild_actions", dict(preset="single_food"), a, seed=22, notes="|a| up to 3, NaN, inf")
 
+    # --- curriculum: base_num_food_items rewritten mid-run (6 slots: 6 -> 2 -> 5 -> 0 -> 3 foods per episode),
+    #     once with a fixed and once with a random food count; short episodes so every value is used
+    sch = [(70, 2), (190, 5), (310, 0), (380, 3)]
+    run_case("curriculum", dict(preset="sac_gail", num_food_items=6, max_steps_without_food=45),
+             uniform_actions(480, 5, 1, 25), seed=26, food_schedule=sch, notes="base_num_food_items poked mid-run")
+    run_case("curriculum_random", dict(preset="sac_gail", num_food_items=6, max_steps_without_food=45,
+                                       random_food_count=True),
+             uniform_actions(480, 5, 1, 27), seed=28, food_schedule=sch, notes="poke + randint(1, base)")
+
     # --- env_index_base: the same global envs from a shard
     run_case("shard_base_1000", dict(preset="single_food_long_horizon"), uniform_actions(128, 4, 1, 23), seed=1001,
              base=1000, notes="global env indices 1000..1003")
@@ -239,4 +270,4 @@ def main():
 if __name__ == "__main__":
     if not rh.reference_available():
         raise SystemExit("reference not found under /root/reference: golden vectors can only be generated in the build container")
-    main()
+    main(only=set(sys.argv[1:]) or None)

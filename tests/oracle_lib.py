@@ -53,6 +53,7 @@ def lib():
         L.salp_oracle_philox4x32_10.restype = None
         L.salp_oracle_global_step.argtypes = [vp]
         L.salp_oracle_global_step.restype = i64
+        L.salp_oracle_set_base_num_food.argtypes = [vp, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -85,6 +86,10 @@ class OracleVec:
                                       ctypes.byref(self._h))
         if rc != 0:
             raise RuntimeError(f"salp_oracle_create failed: {rc}")
+
+    def set_base_num_food(self, k):
+        if lib().salp_oracle_set_base_num_food(self._h, int(k)) != 0:
+            raise ValueError(f"base_num_food_items {k} out of range")
 
     def close(self):
         if self._h:

@@ -29,7 +29,11 @@ def test_hip_matches_reference_vectors(name):
     trunc = np.empty((H, n), np.uint8)
     info = np.empty((n, 3), np.int32)
     # step-by-step through salp_vec_step (info + final_obs), the reference's own call shape
+    sched = {int(t): int(k) for t, k in z["food_schedule"]} if "food_schedule" in z.files else {}
     for t in range(H):
+        if t in sched:          # the curriculum's base_num_food_items poke, through the C ABI
+            dev.set_base_num_food(sched[t])
+            assert dev.base_num_food == sched[t]
         dev.step(act[t], obs[t], rew[t], term[t], trunc[t], fin[t], info, 0)
         assert np.array_equal(info, z["info"][t]), f"info at step {t}"
     assert np.array_equal(term, z["terminated"]) and np.array_equal(trunc, z["truncated"])

@@ -23,7 +23,18 @@ def test_oracle_matches_reference_vectors(name):
     if "inject_f64" in z.files:
         orc.set_state(z["inject_f64"], z["inject_i32"])
     assert np.array_equal(orc.observe(), z["reset_obs"]), "reset observation"
-    out = orc.rollout(act, want_final=True)
+    if "food_schedule" in z.files:      # base_num_food_items pokes: roll out segment by segment
+        cuts = [0] + [int(t) for t, _ in z["food_schedule"]] + [H]
+        ks = [None] + [int(k) for _, k in z["food_schedule"]]
+        parts = []
+        for a, b, k in zip(cuts[:-1], cuts[1:], ks):
+            if k is not None:
+                orc.set_base_num_food(k)
+            if b > a:
+                parts.append(orc.rollout(np.ascontiguousarray(act[a:b]), want_final=True))
+        out = {key: np.concatenate([p[key] for p in parts]) for key in ("terminated", "truncated", "info", "reward64", "obs", "final_obs")}
+    else:
+        out = orc.rollout(act, want_final=True)
     assert np.array_equal(out["terminated"], z["terminated"])
     assert np.array_equal(out["truncated"], z["truncated"])
     assert np.array_equal(out["info"], z["info"])

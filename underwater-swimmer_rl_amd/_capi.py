@@ -27,7 +27,7 @@ EXPORTS = (
     "salp_vec_create", "salp_vec_destroy", "salp_vec_num_envs", "salp_vec_obs_dim", "salp_vec_act_dim",
     "salp_vec_num_food", "salp_vec_device", "salp_vec_reset", "salp_vec_step", "salp_vec_rollout",
     "salp_vec_observe", "salp_vec_get_state", "salp_vec_set_state", "salp_vec_get_stats",
-    "salp_vec_clear_stats", "salp_vec_global_step",
+    "salp_vec_clear_stats", "salp_vec_global_step", "salp_vec_set_base_num_food", "salp_vec_base_num_food",
 )
 
 
@@ -89,6 +89,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.salp_vec_clear_stats.argtypes = [vp]
     L.salp_vec_global_step.argtypes = [vp]
     L.salp_vec_global_step.restype = i64
+    L.salp_vec_set_base_num_food.argtypes = [vp, i32]
+    L.salp_vec_base_num_food.argtypes = [vp]
+    L.salp_vec_base_num_food.restype = i32
     if path is None:
         _lib = L
     return L
@@ -175,6 +178,13 @@ class SalpLib:
 
     def clear_stats(self):
         check(self.lib, self.lib.salp_vec_clear_stats(self._h), "salp_vec_clear_stats")
+
+    @property
+    def base_num_food(self) -> int:
+        return int(self.lib.salp_vec_base_num_food(self._h))
+
+    def set_base_num_food(self, k: int):
+        check(self.lib, self.lib.salp_vec_set_base_num_food(self._h, int(k)), "salp_vec_set_base_num_food")
 
     @property
     def global_step(self) -> int:

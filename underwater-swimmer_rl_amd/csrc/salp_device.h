@@ -48,7 +48,8 @@ struct DevParams {
   double inv_W, inv_H, inv_pi, inv_R, inv_max_nozzle;
   float inv_diag;           // 1/sqrt(W^2+H^2)
   int inhale_dur, exhale_dur, cycle_len, max_steps_wo_food;
-  int F, K;                 // num_food_items, max_observed_food
+  int F, K;                 // food slots (num_food_items at creation), max_observed_food
+  int F_base;               // base_num_food_items: foods of the next episodes, 0..F (snake:36, :144-148)
   int forced, random_food_count, respawn;
   uint32_t seed_lo, seed_hi;
   uint64_t env_base;        // global index of local env 0
@@ -311,10 +312,10 @@ __device__ __forceinline__ int reset_core(EnvCore& e, const DevParams& P, uint64
   e.noz = 0.0; e.water = 0.0; e.epret = 0.0;
   e.packed = pack_breath(0, 0, bw_dur(e.packed), 7);
   e.ssf = 0; e.fc = 0; e.eplen = 0;
-  int nf = P.F;
+  int nf = P.F_base;
   if (P.random_food_count) {  // snake:146 random.randint(1, max(1, base))
     const U4 w = next_block(e, P, genv);
-    const uint32_t n = (uint32_t)(P.F > 1 ? P.F : 1);
+    const uint32_t n = (uint32_t)(P.F_base > 1 ? P.F_base : 1);
     nf = 1 + (int)(((uint64_t)w.x * (uint64_t)n) >> 32);
     if (nf > P.F) nf = P.F;
   }

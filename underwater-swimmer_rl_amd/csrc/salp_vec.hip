@@ -535,6 +535,7 @@ DevParams make_params(const salp_config_t& c, int64_t n, int64_t pitch, uint64_t
   P.cycle_len = c.inhale_duration + c.exhale_duration + c.rest_duration;
   P.max_steps_wo_food = c.max_steps_without_food;
   P.F = c.num_food_items; P.K = c.max_observed_food;
+  P.F_base = c.num_food_items;
   P.forced = c.forced_breathing != 0; P.random_food_count = c.random_food_count != 0;
   P.respawn = c.respawn_food != 0;
   P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
@@ -755,6 +756,14 @@ int salp_vec_act_dim(const salp_vec_t* h) { return h ? h->act_dim : 0; }
 int salp_vec_num_food(const salp_vec_t* h) { return h ? h->F : 0; }
 int salp_vec_device(const salp_vec_t* h) { return h ? h->device : -1; }
 int64_t salp_vec_global_step(const salp_vec_t* h) { return h ? h->global_step : 0; }
+
+int salp_vec_set_base_num_food(salp_vec_t* h, int32_t k) {
+  if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
+  if (k < 0 || k > h->P.F) return fail(SALP_ERR_INVALID, "base_num_food_items must be within 0..num_food_items of the handle");
+  h->P.F_base = k;     // kernel parameters are passed by value at every launch
+  return SALP_OK;
+}
+int32_t salp_vec_base_num_food(const salp_vec_t* h) { return h ? h->P.F_base : 0; }
 
 int salp_vec_reset(salp_vec_t* h, const uint8_t* mask, float* obs, uint32_t flags, void* stream) {
   if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");

@@ -112,9 +112,13 @@ class SalpVectorEnv:
         """Resets every env (or those in `mask`).  `seed` re-keys the draw streams (the reference's
         reset(seed) only seeds gymnasium's unused np_random, snake:136)."""
         if seed is not None and int(seed) != self.seed_value:
+            base_food = self._lib.base_num_food
             self._lib.close()
             self.seed_value = int(seed)
             self._lib = SalpLib(self.cfg, self.num_envs, self._device_index, self.seed_value, self.env_index_base)
+            if base_food != self.cfg.num_food_items:      # a poked base_num_food_items survives re-seeding
+                self._lib.set_base_num_food(base_food)
+                self._lib.reset(None, self._buf("obs", (self.num_envs, self.obs_dim), np.float32), self._flags, self._stream)
             self._step_cache = None
             obs = self._buf("obs", (self.num_envs, self.obs_dim), np.float32)
             self._lib.observe(obs, self._flags, self._stream)
@@ -304,6 +308,16 @@ class SalpVectorEnv:
         F = self.cfg.num_food_items
         return np.stack([f[_capi.F_FOOD0:_capi.F_FOOD0 + F].T, f[_capi.F_FOOD0 + F:_capi.F_FOOD0 + 2 * F].T], axis=2)
 
+    @property
+    def base_num_food_items(self) -> int:
+        """The attribute the reference's curriculum writes (continuous_trainer.py:409-411; snake:36): foods
+        placed at every later reset, 0..cfg.num_food_items (the slots the env was created with)."""
+        return self._lib.base_num_food
+
+    @base_num_food_items.setter
+    def base_num_food_items(self, k: int):
+        self._lib.set_base_num_food(k)
+
     def stats(self) -> dict:
         return self._lib.stats()
 
@@ -390,9 +404,14 @@ class SalpSB3VecEnv:
         if hasattr(self.venv.cfg, attr_name):
             return [getattr(self.venv.cfg, attr_name)] * len(idx)
         v = getattr(self.venv, attr_name)
+        if np.ndim(v) == 0:
+            return [v] * len(idx)
         return [v[i] for i in idx]
 
     def set_attr(self, attr_name, value, indices=None):
+        if attr_name == "base_num_food_items":      # the one parameter the reference's trainers poke
+            self.venv.base_num_food_items = value
+            return
         raise AttributeError(f"{attr_name}: parameters are fixed at construction; state goes through set_state()")
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
