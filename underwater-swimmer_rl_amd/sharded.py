@@ -55,6 +55,7 @@ class ShardedSalpVectorEnv:
         self.obs_dim, self.act_dim = self.cfg.obs_dim, self.cfg.act_dim
         self._pending = None
         self._gbuf = {}
+        self._pack = None
 
     # ------------------------------------------------------------------ collectives
     def _out(self, name, local: torch.Tensor):
@@ -96,15 +97,22 @@ class ShardedSalpVectorEnv:
         return self.all_gather("obs", obs), info
 
     def step(self, actions):
-        """Every rank returns the full [N, ...] batch (obs, reward, terminated, truncated)."""
+        """Every rank returns the full [N, ...] batch (obs, reward, terminated, truncated).  One collective per
+        step: observation, reward and the two flags travel as one [N/G, obs_dim + 2] float32 block (a ring
+        all-gather over xGMI is latency-bound at this size; three separate ones cost three launches)."""
         a = self._shard(actions, 0)
         obs, rew, term, trunc, info = self.engine.step(a)
-        g_obs = self.all_gather("obs", obs)
-        g_rew = self.all_gather("reward", rew)
-        flags = torch.stack([_to_tensor(term, self.device).to(torch.uint8),
-                             _to_tensor(trunc, self.device).to(torch.uint8)], dim=1)
-        g_flags = self.all_gather("flags", flags)
-        return g_obs, g_rew, g_flags[:, 0].bool(), g_flags[:, 1].bool(), info
+        obs, rew = _to_tensor(obs, self.device), _to_tensor(rew, self.device)
+        flags = _to_tensor(term, self.device).to(torch.float32) + 2.0 * _to_tensor(trunc, self.device).to(torch.float32)
+        pack = self._pack
+        if pack is None or pack.shape[0] != obs.shape[0] or pack.device != obs.device:
+            pack = self._pack = torch.empty((obs.shape[0], self.obs_dim + 2), dtype=torch.float32, device=obs.device)
+        pack[:, :self.obs_dim] = obs
+        pack[:, self.obs_dim] = rew
+        pack[:, self.obs_dim + 1] = flags
+        g = self.all_gather("step", pack)
+        gf = g[:, self.obs_dim + 1]
+        return g[:, :self.obs_dim], g[:, self.obs_dim], (gf == 1.0) | (gf == 3.0), gf >= 2.0, info
 
     def rollout(self, actions=None, horizon=None, gather: str = "final", async_gather: bool = False):
         """Local fused rollout of `horizon` steps, then the exchange:
