@@ -50,7 +50,10 @@ __device__ __forceinline__ void scan_foods(const FoodLds& f, int F, double x, do
   int cnt = 0;
   collected = false;
   hit_k = 0;
-#pragma unroll 2
+#ifndef SALP_SCAN_UNROLL
+#define SALP_SCAN_UNROLL 4
+#endif
+#pragma unroll SALP_SCAN_UNROLL
   for (int k = 0; k < F; ++k) {
     double fx, fy;
     f.get(k, fx, fy);
