@@ -82,3 +82,33 @@ def test_cycle_length_schedule_does_not_change_results(monkeypatch):
     for r0, r1 in zip(*outs):
         for x0, x1 in zip(r0, r1):
             assert np.array_equal(x0, x1, equal_nan=True)
+
+
+def test_hip_robot_full_batch_sampled_parity():
+    """65536 robots (above the size where the longest-cycle-first schedule switches on by itself), 8 cycles with
+    cycle lengths from 0 to 14.5 s: 160 sampled robots against the oracle, each keyed by its global index."""
+    n, seed, T = 65536, 21, 8
+    env = SalpRobotVectorEnv(n, device="cuda:0", seed=seed)
+    sample = np.unique(np.concatenate([np.arange(0, n, n // 80)[:80], np.arange(0, n, n // 80)[:80] + 1]))
+    oracles = [rol.RobotOracleVec(1, seed=seed, env_index_base=int(i)) for i in sample]
+    for o in oracles:
+        o.reset(np.zeros(1, np.uint8))
+    rng = np.random.default_rng(8)
+    total_inner = 0
+    for t in range(T):
+        a = np.stack([rng.uniform(0, 1, n), rng.uniform(0, 1, n), rng.uniform(-1, 1, n)], axis=1).astype(np.float32)
+        obs, rew, term, trunc, info = env.step(a)
+        obs, rew, term, trunc = (x.cpu().numpy() for x in (obs, rew, term, trunc))
+        inner = info["inner_steps"].cpu().numpy()
+        total_inner += int(inner.sum())
+        for j, i in enumerate(sample):
+            ref = oracles[j].step(a[i:i + 1])
+            assert inner[i] == ref["inner_steps"][0], (t, i)
+            assert bool(term[i]) == bool(ref["terminated"][0]) and bool(trunc[i]) == bool(ref["truncated"][0]), (t, i)
+            assert rel(obs[i], ref["obs"][0]) <= TOL and rel(rew[i], ref["reward"][0]) <= 1e-5, (t, i)
+    state = env.get_state()
+    for j, i in enumerate(sample):
+        assert rel(state[:, i], oracles[j].get_state()[:, 0]) <= TOL, i
+        oracles[j].close()
+    assert total_inner > n * T * 300
+    env.close()
