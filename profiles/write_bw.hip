@@ -47,6 +47,30 @@ __global__ __launch_bounds__(256) void slab_kernel(v4f* obs, float* rew, unsigne
   }
 }
 
+// (2c) the rollout pattern with everything the real kernel moves: the per-step action read (4 B/lane, prefetched
+// one step ahead, consumed so it cannot be dropped) and the small stores issued BEFORE the observation rows
+template <bool READ, bool SMALL_FIRST>
+__global__ __launch_bounds__(256) void full_kernel(v4f* obs, float* rew, unsigned char* f0, unsigned char* f1, const float* act, int H, size_t N) {
+  const int lane = threadIdx.x & 63;
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const size_t env = w * 64 + lane;
+  float a = READ ? act[env] : 1.f;
+  float acc = 0.f;
+#pragma unroll 1
+  for (int t = 0; t < H; ++t) {
+    const float cur = a;
+    if (READ) a = act[(size_t)(t + 1 < H ? t + 1 : t) * N + env];
+    acc += cur;
+    const v4f v = {cur, acc, 3.f, 4.f};
+    if (SMALL_FIRST) { rew[(size_t)t * N + env] = acc; f0[(size_t)t * N + env] = 0; f1[(size_t)t * N + env] = 1; }
+    v4f* p = obs + ((size_t)t * N + w * 64) * 6 + lane;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(v, &p[j * 64]);
+    if (!SMALL_FIRST) { rew[(size_t)t * N + env] = acc; f0[(size_t)t * N + env] = 0; f1[(size_t)t * N + env] = 1; }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+}
+
 // (2b) "fat wavefronts": each lane owns E envs, a wavefront 64 E consecutive envs: per step it writes E x 6144
 // contiguous bytes (6 E instructions) and there are E times fewer wavefronts.  WPB wavefronts per block.
 template <int E, int WPB, bool DRAIN, bool SMALL>
@@ -113,7 +137,7 @@ int main() {
   const double gb = obs_bytes / 1e9, gb_small = gb + (double)H * N * 6 / 1e9;
   auto rep = [&](const char* name, double ms, double g) { printf("%-58s %7.3f ms  %6.2f TB/s\n", name, ms, g / ms); fflush(stdout); };
   for (int threads : {256, 1024})
-    for (int blocks : {256, 768, 1024, 1280, 16384, 262144}) {
+    for (int blocks : {256, 1024}) {
       char nm[96];
       snprintf(nm, sizeof nm, "flat grid-stride, %d x %d threads (window %.1f MB), plain", blocks, threads, blocks * (double)threads * 16 / 1e6);
       rep(nm, time_ms([&] { hipLaunchKernelGGL(flat_kernel<false>, dim3(blocks), dim3(threads), 0, 0, obs, n4); }, 5), gb);
@@ -124,6 +148,12 @@ int main() {
   rep("rollout pattern, nt, drain per step", time_ms([&] { hipLaunchKernelGGL((slab_kernel<true, true, false>), dim3(G), dim3(256), 0, 0, obs, rew, f0, f1, H, N); }), gb);
   rep("rollout pattern, nt, drain, + reward and flag streams", time_ms([&] { hipLaunchKernelGGL((slab_kernel<true, true, true>), dim3(G), dim3(256), 0, 0, obs, rew, f0, f1, H, N); }), gb_small);
   rep("rollout pattern, nt, no drain, + reward and flag streams", time_ms([&] { hipLaunchKernelGGL((slab_kernel<true, false, true>), dim3(G), dim3(256), 0, 0, obs, rew, f0, f1, H, N); }), gb_small);
+  float* act; CHECK(hipMalloc(&act, (size_t)H * N * 4)); CHECK(hipMemset(act, 0, (size_t)H * N * 4));
+  const double gb_all = gb_small + (double)H * N * 4 / 1e9;
+  rep("full: obs + small stores after, no action read", time_ms([&] { hipLaunchKernelGGL((full_kernel<false, false>), dim3(G), dim3(256), 0, 0, obs, rew, f0, f1, act, H, N); }), gb_small);
+  rep("full: obs + small stores first, no action read", time_ms([&] { hipLaunchKernelGGL((full_kernel<false, true>), dim3(G), dim3(256), 0, 0, obs, rew, f0, f1, act, H, N); }), gb_small);
+  rep("full: obs + small stores after + action read", time_ms([&] { hipLaunchKernelGGL((full_kernel<true, false>), dim3(G), dim3(256), 0, 0, obs, rew, f0, f1, act, H, N); }), gb_all);
+  rep("full: obs + small stores first + action read (the kernel's stream)", time_ms([&] { hipLaunchKernelGGL((full_kernel<true, true>), dim3(G), dim3(256), 0, 0, obs, rew, f0, f1, act, H, N); }), gb_all);
 #define FAT(E, WPB, DR, SM, label) rep(label, time_ms([&] { hipLaunchKernelGGL((fat_kernel<E, WPB, DR, SM>), dim3((unsigned)(N / (64 * E * WPB))), dim3(64 * WPB), 0, 0, obs, rew, f0, f1, H, N); }), SM ? gb_small : gb)
   FAT(1, 4, true, false, "fat E=1 (64 envs/wavefront), 4 waves/block, drain");
   FAT(2, 4, true, false, "fat E=2 (128 envs/wavefront), 4 waves/block, drain");
