@@ -640,15 +640,19 @@ struct Bump {  // carve sub-buffers out of the staging allocation
 int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
   const bool full = io.obs && io.reward && io.terminated && io.truncated && !io.final_obs && !io.info;
   const bool gen = io.act == nullptr;               // only reached when can_generate_in_kernel()
-  const int64_t n_full = h->n / kWave * kWave;      // envs in full wavefronts: unpredicated kernel
+  int64_t n_full = h->n / kWave * kWave;            // envs in full wavefronts: unpredicated kernel
+  // A small ragged batch (step-per-launch acting loops) is launch-bound: one predicated launch over the whole
+  // range instead of two; the predicates only cost when the write stream is the bound.
+  if (n_full < h->n && h->n * (int64_t)H <= (int64_t)1 << 22) n_full = 0;
   if (n_full > 0) {
     const unsigned grid = (unsigned)((n_full + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(rollout_kernel_for<false>(h, full, gen), dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
                        (int64_t)0, n_full);
     HIP_TRY(hipGetLastError());
   }
-  if (n_full < h->n) {                              // the last n % 64 envs: one predicated wavefront
-    hipLaunchKernelGGL(rollout_kernel_for<true>(h, full, gen), dim3(1), dim3(kBlock), 0, st, h->P, h->S, io, H,
+  if (n_full < h->n) {                              // the last n % 64 envs (or the whole small batch): predicated stores
+    const unsigned rgrid = (unsigned)((h->n - n_full + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(rollout_kernel_for<true>(h, full, gen), dim3(rgrid), dim3(kBlock), 0, st, h->P, h->S, io, H,
                        n_full, h->n);
     HIP_TRY(hipGetLastError());
   }
