@@ -323,3 +323,45 @@ def test_create_rejects_bad_arguments():
     h = ctypes.c_void_p()
     assert lib.salp_vec_create(ctypes.byref(c), 16, 0, 0, 0, ctypes.byref(h)) == -1
     assert b"struct_size" in lib.salp_last_error()
+
+
+def _random_cfg(rng):
+    """A random but valid environment: food slots 0..16, observed foods 0..8, every flag, non-default tank,
+    radii, drag, thrust and durations (the generic <16, 8> instantiation and the LDS food path), or the
+    reference's constants with random flags (the STD instantiations)."""
+    std = rng.random() < 0.4
+    kw = dict(num_food_items=int(rng.integers(0, 17)), max_observed_food=int(rng.integers(0, 9)) if not std else 3,
+              forced_breathing=bool(rng.random() < 0.6), random_food_count=bool(rng.random() < 0.3),
+              respawn_food=bool(rng.random() < 0.7), proximity_reward_weight=float(rng.choice([0.0, 0.5, 5.0])),
+              efficiency_bonus=float(rng.choice([0.0, 1.0])), max_steps_without_food=int(rng.integers(20, 400)),
+              food_reward=float(rng.uniform(1, 20)), collision_penalty=float(-rng.uniform(1, 60)),
+              time_penalty=float(-rng.uniform(0, 0.5)))
+    if not std:
+        kw.update(width=int(rng.integers(500, 1200)), height=int(rng.integers(450, 900)),
+                  tank_margin=float(rng.uniform(20, 60)), base_radius=float(rng.uniform(18, 34)),
+                  max_thrust_force=float(rng.uniform(60, 160)), drag_coefficient=float(rng.uniform(0.95, 0.995)),
+                  angular_drag=float(rng.uniform(0.9, 0.99)), max_nozzle_angle=float(rng.uniform(0.6, 1.3)),
+                  nozzle_response_rate=float(rng.uniform(0.02, 0.2)), food_radius=float(rng.uniform(8, 25)),
+                  min_food_distance=float(rng.uniform(40, 110)))
+        if rng.random() < 0.5:      # other breathing timings than the legacy 120 / 150 / 60
+            kw.update(inhale_duration=int(rng.integers(10, 200)), exhale_duration=int(rng.integers(20, 250)),
+                      rest_duration=int(rng.integers(0, 120)))
+    return pkg.SalpSnakeConfig(**kw)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_configuration_parity(case):
+    rng = np.random.default_rng(1000 + case)
+    cfg = _random_cfg(rng)
+    n, H, seed = 777, 260, int(rng.integers(0, 2 ** 31))          # ragged last wavefront
+    act = make_actions(cfg, H, n, seed=case, scale=1.2)            # a little outside the Box too
+    got, dev = run_device(cfg, n, act, seed=seed, want_final=True)
+    orc = ol.OracleVec(cfg, n, seed=seed)
+    ref = orc.rollout(act, want_final=True)
+    assert_parity(cfg, got, ref, f"random case {case}: {cfg}")
+    assert_state_parity(cfg, dev, orc, f"random case {case}")
+    done = (ref["terminated"] | ref["truncated"]).astype(bool)
+    if done.any():
+        assert obs_diff(cfg, got["final_obs"][done], ref["final_obs"][done]).max() <= OBS_TOL
+    dev.close()
+    orc.close()
