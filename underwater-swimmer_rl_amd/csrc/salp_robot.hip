@@ -70,6 +70,23 @@ __device__ __forceinline__ void sincos_euler(double x, double& s, double& c) {
 }
 __device__ __forceinline__ double sq(double x) { return x * x; }
 
+// (s, c) <- sin / cos of (angle + d) from sin / cos of the angle, |d| <= 0.25 rad: Taylor polynomials of sin d and
+// cos d (truncation < 1e-16) and the angle-addition formulas; ~16 operations instead of a full sincos.
+__device__ __forceinline__ void rotate_sincos(double& s, double& c, double d) {
+  const double z = d * d;
+  double ps = fma(z, 2.7557319223985893e-06, -1.9841269841269841e-04);    // 1/9!, -1/7!
+  ps = fma(z, ps, 8.3333333333333332e-03);
+  ps = fma(z, ps, -1.6666666666666666e-01);
+  const double sd = fma(d * z, ps, d);
+  double pc = fma(z, -2.7557319223985888e-07, 2.4801587301587302e-05);    // -1/10!, 1/8!
+  pc = fma(z, pc, -1.3888888888888889e-03);
+  pc = fma(z, pc, 4.1666666666666664e-02);
+  pc = fma(z, pc, -0.5);
+  const double cd = fma(z, pc, 1.0);
+  const double ns = fma(s, cd, c * sd), nc = fma(c, cd, -(s * sd));
+  s = ns; c = nc;
+}
+
 // 1/x for a normal, finite x: v_rcp_f64 and two Newton steps (<= 1 ulp; no range scaling / fix-up pass)
 __device__ __forceinline__ double rcp_nr(double x) {
   double y = __builtin_amdgcn_rcp(x);
@@ -317,9 +334,13 @@ void salp_robot_step_kernel(RobotParams P, RobotState S, const float* act, float
   const double t_jet_end = refill_time + jet_time, t_coast_end = t_jet_end + coast_time;
   double mass = 0, inv_m = 0, kd = 0, ktc = 0, ax = 0, I0 = 0, I1 = 0, I2 = 0, iI0 = 0, iI1 = 0, iI2 = 0;
   bool settled = false;    // the previous step of this lane already had the rest shape (and prevI == I)
-  double sp, cp, st, ct;
+  // sin / cos of the three Euler angles are carried through the cycle: exact at its start, then advanced by each
+  // step's increment with rotate_sincos (increments are ~1e-3 rad; an increment above 0.25 rad anywhere in the
+  // wavefront takes the exact path for that step).  Drift over a whole cycle stays below 1e-12.
+  double sp, cp, st, ct, ss, cs;
   sincos_euler(r.eul[0], sp, cp);
   sincos_euler(r.eul[1], st, ct);
+  sincos_euler(r.eul[2], ss, cs);
 #pragma unroll 1
   while (__any(cycle_time < total)) {
     if (cycle_time < total) {
@@ -402,13 +423,19 @@ void salp_robot_step_kernel(RobotParams P, RobotState S, const float* act, float
         const double e0 = r.om[0] + (sp * tt) * r.om[1] + (cp * tt) * r.om[2];
         const double e1 = cp * r.om[1] + (-sp) * r.om[2];
         const double e2 = (sp * ict) * r.om[1] + (cp * ict) * r.om[2];
-        r.eul[0] += e0 * dt; r.eul[1] += e1 * dt; r.eul[2] += e2 * dt;
+        const double d0 = e0 * dt, d1 = e1 * dt, d2 = e2 * dt;
+        r.eul[0] += d0; r.eul[1] += d1; r.eul[2] += d2;
+        if (__any(fabs(d0) > 0.25 || fabs(d1) > 0.25 || fabs(d2) > 0.25)) {
+          sincos_euler(r.eul[0], sp, cp);
+          sincos_euler(r.eul[1], st, ct);
+          sincos_euler(r.eul[2], ss, cs);
+        } else {
+          rotate_sincos(sp, cp, d0);
+          rotate_sincos(st, ct, d1);
+          rotate_sincos(ss, cs, d2);
+        }
       }
       {
-        double ss, cs;
-        sincos_euler(r.eul[0], sp, cp);
-        sincos_euler(r.eul[1], st, ct);
-        sincos_euler(r.eul[2], ss, cs);
         // R = R_z @ R_y @ R_x
         const double r00 = cs * ct, r01 = cs * st * sp - ss * cp, r02 = cs * st * cp + ss * sp;
         const double r10 = ss * ct, r11 = ss * st * sp + cs * cp, r12 = ss * st * cp - cs * sp;
