@@ -322,7 +322,7 @@ void salp_robot_step_kernel(RobotParams P, RobotState S, const float* act, float
   //  * quantities that depend only on the body shape (mass, inertia, drag factors and their reciprocals)
   //    are kept in registers and recomputed only on a step where some lane's shape moves or has just
   //    stopped moving; during coast / rest (most of a cycle) the whole wavefront skips that block;
-  //  * sin/cos of roll and pitch after the kinematic update are the ones the next step starts with;
+  //  * sin/cos of the Euler angles are carried from step to step (see rotate_sincos below in the loop);
   //  * divisions by dt, by cos(pitch) and by the mass / inertia diagonal are reciprocals (Newton-refined
   //    v_rcp_f64) times a product: a few ulp from the reference's quotient, far inside the parity
   //    tolerance, which is a tolerance already because the reference multiplies 3x3 blocks through BLAS.
