@@ -194,14 +194,16 @@ class SAC:
         for p in self.critic_target.parameters():
             p.requires_grad_(False)
         # capturable Adam keeps its step count on the device, so `update` can live inside a hipGraph
+        # (and fused: one multi-tensor kernel per optimiser step instead of a dozen small ones per parameter)
         cap = self.device.type == "cuda"
-        self.actor_opt = torch.optim.Adam(self.actor.parameters(), lr=cfg.learning_rate, capturable=cap)
-        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=cfg.learning_rate, capturable=cap)
+        kw = dict(capturable=True, fused=True) if cap else {}
+        self.actor_opt = torch.optim.Adam(self.actor.parameters(), lr=cfg.learning_rate, **kw)
+        self.critic_opt = torch.optim.Adam(self.critic.parameters(), lr=cfg.learning_rate, **kw)
         # train.py:60-70 leaves ent_coef at SB3's "auto"; SB3SACAgent passes the YAML alpha (fixed)
         self.learn_alpha = (cfg.alpha is None) if learn_alpha is None else learn_alpha
         init_alpha = 1.0 if cfg.alpha is None else float(cfg.alpha)
         self.log_alpha = torch.tensor(math.log(init_alpha), device=self.device, requires_grad=self.learn_alpha)
-        self.alpha_opt = torch.optim.Adam([self.log_alpha], lr=cfg.alpha_lr, capturable=cap) if self.learn_alpha else None
+        self.alpha_opt = torch.optim.Adam([self.log_alpha], lr=cfg.alpha_lr, **kw) if self.learn_alpha else None
         self.target_entropy = -float(act_dim) if cfg.target_entropy is None else float(cfg.target_entropy)
         self.updates = 0
         self.world = 1
@@ -267,9 +269,10 @@ class SAC:
             alpha_loss.backward()
             self._average_grads([self.log_alpha])
             self.alpha_opt.step()
-        with torch.no_grad():  # polyak update (core/base_agent.py:63-74 soft_update)
-            for p, tp in zip(self.critic.parameters(), self.critic_target.parameters()):
-                tp.mul_(1.0 - self.cfg.tau).add_(p, alpha=self.cfg.tau)
+        with torch.no_grad():  # polyak update (core/base_agent.py:63-74 soft_update), two multi-tensor kernels
+            tps, ps = list(self.critic_target.parameters()), list(self.critic.parameters())
+            torch._foreach_mul_(tps, 1.0 - self.cfg.tau)
+            torch._foreach_add_(tps, ps, alpha=self.cfg.tau)
         self.updates += 1
         return {"critic_loss": critic_loss.detach(), "actor_loss": actor_loss.detach(),
                 "alpha": self.log_alpha.exp().detach(), "entropy": -logp.detach().mean()}
