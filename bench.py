@@ -119,6 +119,7 @@ def main():
     if world > 1 or force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # RCCL's stream ahead of the rollout launches in the dispatcher
         if force_sharded:
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
         else:
@@ -159,18 +160,16 @@ def main():
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for k in range(K):
-        if senv is not None:
-            senv.wait_gather()               # previous chunk's gather must be done before its buffer is reused
         starts[k].record()
         if senv is not None:
             out = senv.engine.rollout(act)
             ends[k].record()
             if args.gather == "final":
-                g, work = senv.all_gather("final_obs", out["obs"][-1], async_op=True)
-                senv._pending = work
+                # staged + double-buffered: the next launch starts at once, the collective runs beside it
+                senv.gather_final_async(out["obs"][-1])
             elif args.gather == "all":
                 g, work = senv.all_gather("all_obs", out["obs"].reshape(1, H, n, cfg.obs_dim), async_op=True)
-                senv._pending = work
+                work.wait()                  # the block is overwritten by the next launch: xGMI-bound by construction
         else:
             env.rollout(act)
             ends[k].record()

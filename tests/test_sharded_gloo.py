@@ -69,7 +69,19 @@ def _worker(rank, world, port, tmp):
         env.wait_gather()
         _, g_none = env.rollout(torch.from_numpy(act[:5]), gather="none")
         assert g_none is None
+        # three launches with the staged, double-buffered asynchronous gather in flight (bench.py's pattern):
+        # slot 0, slot 1, slot 0 again; each gathered block must be its own launch's last observation
+        asy = []
+        for i in range(3):
+            _, g = env.rollout(torch.from_numpy(act[20 + 4 * i: 24 + 4 * i]), gather="final", async_gather=True)
+            if i == 1:
+                env.wait_gather()
+                asy.append(g.numpy().copy())      # launch 1, read before its slot partner is reused
+            elif i == 2:
+                env.wait_gather()
+                asy.append(g.numpy().copy())      # launch 2 went through slot 0 again
         np.savez(os.path.join(tmp, f"rank{rank}.npz"), obs0=obs0.numpy(), g_final=g_final.numpy(), g_all=g_all.numpy(),
+                 g_async1=asy[0], g_async2=asy[1],
                  **{f"s{t}_{k}": v for t, s in enumerate(steps) for k, v in zip(("obs", "rew", "term", "trunc"), s)})
         env.close()
     finally:
@@ -102,6 +114,10 @@ def test_two_rank_sharding_equals_single_process(tmp_path):
     g_all = r0["g_all"]                                                      # [G, H, n_local, D]
     assert g_all.shape == (2, 10, 32, cfg.obs_dim)
     assert np.array_equal(np.concatenate([g_all[0], g_all[1]], axis=1), out["obs"])
+    one.rollout(act[:5])                                                      # the gather="none" launch
+    one.rollout(act[20:24])
+    assert np.array_equal(r0["g_async1"], one.rollout(act[24:28])["obs"][-1])
+    assert np.array_equal(r0["g_async2"], one.rollout(act[28:32])["obs"][-1])
 
 
 def _sac_worker(rank, world, port, tmp):

@@ -53,9 +53,10 @@ class ShardedSalpVectorEnv:
             self.engine = engine_factory(self.cfg, self.local_envs, seed, self.env_index_base)
             self.device = torch.device("cpu")
         self.obs_dim, self.act_dim = self.cfg.obs_dim, self.cfg.act_dim
-        self._pending = None
+        self._pending = []
         self._gbuf = {}
         self._pack = None
+        self._slot, self._slot_work, self._stage = 0, [None, None], [None, None]
 
     # ------------------------------------------------------------------ collectives
     def _out(self, name, local: torch.Tensor):
@@ -121,28 +122,58 @@ class ShardedSalpVectorEnv:
                         "none": no exchange (data-parallel learners).
         Returns (local_outputs, gathered_obs_or_None).  With async_gather the collective overlaps
         the caller's next launch; call wait_gather() before reading the gathered tensor."""
-        self.wait_gather()
+        if not (gather == "final" and async_gather):
+            self.wait_gather()       # "all" reads the rollout's own output block: it must not be overwritten under it
         a = self._shard(actions, 1)
         out = self.engine.rollout(a, horizon)
         g = None
         if gather == "final":
-            g = self.all_gather("final_obs", out["obs"][-1], async_op=async_gather)
+            if async_gather:
+                g = self.gather_final_async(out["obs"][-1])
+            else:
+                g = self.all_gather("final_obs", out["obs"][-1])
         elif gather == "all":
             H = out["obs"].shape[0]
             # [H, n, D] -> rank-major blocks; viewed back as [G, H, n, D] by the caller
             g = self.all_gather("all_obs", _to_tensor(out["obs"], self.device).reshape(1, H, self.local_envs, self.obs_dim),
                                 async_op=async_gather)
+            if async_gather:
+                self._pending.append(g[1])
+                g = g[0]
         elif gather != "none":
             raise ValueError("gather must be 'final', 'all' or 'none'")
-        if async_gather and g is not None:
-            self._pending = g[1]
-            g = g[0]
         return out, g
 
+    def gather_final_async(self, final_obs):
+        """Asynchronous all-gather of one [N/G, obs_dim] block that does not pin the rollout's output buffer:
+        the block is first copied (25 MB at N/G = 262144: ~10 us) into one of two staging buffers on the compute
+        stream, and the collective reads the staging copy.  The next launch — which overwrites the rollout's
+        output block — can therefore start at once, and the collective runs beside it on RCCL's own stream; a
+        staging slot is only waited for when it comes round again, two launches later.  Returns the gathered
+        tensor of this slot (valid after wait_gather())."""
+        slot = self._slot
+        self._slot ^= 1
+        w = self._slot_work[slot]
+        if w is not None:            # the collective that last used this slot (two launches ago)
+            w.wait()
+            self._slot_work[slot] = None
+        local = _to_tensor(final_obs, self.device)
+        st = self._stage[slot]
+        if st is None or st.shape != local.shape or st.device != local.device:
+            st = self._stage[slot] = torch.empty_like(local, memory_format=torch.contiguous_format)
+        st.copy_(local)
+        g, work = self.all_gather(f"final_obs{slot}", st, async_op=True)
+        self._slot_work[slot] = work
+        return g
+
     def wait_gather(self):
-        if self._pending is not None:
-            self._pending.wait()
-            self._pending = None
+        for i, w in enumerate(self._slot_work):
+            if w is not None:
+                w.wait()
+                self._slot_work[i] = None
+        for w in self._pending:
+            w.wait()
+        self._pending = []
 
     def close(self):
         self.wait_gather()
