@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=250, help="env-steps per fused rollout launch")
     ap.add_argument("--preset", default="single_food_long_horizon")
     ap.add_argument("--gather", default="final", choices=["final", "all", "none"])
+    ap.add_argument("--actions", default="hbm", choices=["hbm", "generated"],
+                    help="hbm: a random action block resident in HBM, read by the kernel; generated: the kernel draws the "
+                         "actions from each env's Philox action stream and writes them out (same 4 B per env-step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -139,12 +142,15 @@ def main():
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     act = torch.rand((H, n, cfg.act_dim), generator=gen, device=device, dtype=torch.float32) * 2.0 - 1.0
+    if args.actions == "generated":
+        act = None      # salp_vec_rollout(act = NULL, act_out = buffer): SURVEY.md §8d config 3 "generated on device"
+    rkw = {} if act is not None else {"horizon": H}
 
     def one_launch():
         if senv is not None:
-            senv.rollout(act, gather=args.gather, async_gather=True)
+            senv.rollout(act, gather=args.gather, async_gather=True, **rkw)
         else:
-            env.rollout(act)
+            env.rollout(act, **rkw)
 
     for _ in range(W):
         one_launch()
@@ -162,7 +168,7 @@ def main():
     for k in range(K):
         starts[k].record()
         if senv is not None:
-            out = senv.engine.rollout(act)
+            out = senv.engine.rollout(act, **rkw)
             ends[k].record()
             if args.gather == "final":
                 # staged + double-buffered: the next launch starts at once, the collective runs beside it
@@ -171,7 +177,7 @@ def main():
                 g, work = senv.all_gather("all_obs", out["obs"].reshape(1, H, n, cfg.obs_dim), async_op=True)
                 work.wait()                  # the block is overwritten by the next launch: xGMI-bound by construction
         else:
-            env.rollout(act)
+            env.rollout(act, **rkw)
             ends[k].record()
     if senv is not None:
         senv.wait_gather()
@@ -212,7 +218,8 @@ def main():
         "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[2]: N_envs={n}/GPU {args.preset}, {H * K}-step rollout as {K} fused launches of {H} steps, random actions in HBM",
+            "workload": f"BASELINE configs[2]: N_envs={n}/GPU {args.preset}, {H * K}-step rollout as {K} fused launches of {H} steps, " +
+                        ("random actions in HBM" if act is not None else "random actions drawn in the kernel and written out"),
             "envs_per_gpu": n, "chunk": H, "obs_dim": cfg.obs_dim, "act_dim": cfg.act_dim,
             "parallelism": f"env-sharded x{world}" + (f", all-gather {args.gather} obs" if senv is not None else ""),
             "env_steps_per_bench_step": n * H * world,
