@@ -112,3 +112,19 @@ def test_hip_robot_full_batch_sampled_parity():
         oracles[j].close()
     assert total_inner > n * T * 300
     env.close()
+
+
+def test_sac_learner_runs_on_the_robot_env():
+    """train_robot.py's consumer side: the SAC learner (its hyper-parameters) on the batched HEAD simulator, eager and
+    hipGraph-captured."""
+    from underwater_swimmer_rl_amd.sac import SAC, SACConfig, train_sac, train_sac_graphed
+    for run in (train_sac, train_sac_graphed):
+        env = SalpRobotVectorEnv(256, device="cuda:0", seed=1)
+        cfg = SACConfig.from_preset("salp_robot")
+        cfg.learning_starts = 4
+        agent = SAC(env.obs_dim, env.act_dim, cfg, device="cuda:0", seed=0,
+                    act_low=env.single_action_space.low, act_high=env.single_action_space.high)
+        m = run(env, agent, 24)
+        assert m["vector_steps"] == 24 and m["updates"] == 20
+        assert all(np.isfinite(m[k]) for k in ("critic_loss", "actor_loss", "alpha", "entropy"))
+        env.close()

@@ -168,6 +168,8 @@ class SACConfig:
 
 # `agent:` blocks of configs/single_food.yaml:20-33, single_food_long_horizon.yaml:20-33, sac_gail.yaml:16-29
 AGENT_PRESETS: Dict[str, dict] = {
+    # src/salp/environments/train_robot.py:39-47 (the HEAD simulator's SAC: ent_coef "auto", batch 512, buffer 1e5)
+    "salp_robot": dict(batch_size=512, buffer_size=100_000, gamma=0.99, tau=0.005, alpha=None, target_entropy=None),
     "single_food": dict(batch_size=128, buffer_size=500_000, gamma=0.99, tau=0.005, alpha=0.5, target_entropy=-0.5),
     "single_food_long_horizon": dict(batch_size=256, buffer_size=100_000, gamma=0.995, tau=0.005, alpha=0.2,
                                      target_entropy=-0.5),
@@ -324,7 +326,9 @@ def train_sac(env, agent: SAC, total_vector_steps: int, buffer: Optional[DeviceR
             finished_returns += float(ep_returns[done].sum())
             finished += int(done.sum())
             ep_returns[done] = 0.0
-        got_food = (info["food_collected"] > 0).any()
+        # "first food capture" for SalpSnakeEnv; for envs without a food counter (the HEAD SalpRobotEnv) the first
+        # termination, i.e. the first robot that reaches its target (salp_robot_env.py:176-178)
+        got_food = (info["food_collected"] > 0).any() if "food_collected" in info else term.any()
         if agent.world > 1 and first_food_s is None:   # every rank must take the same branch (the updates are collective)
             import torch.distributed as dist
             flag = got_food.to(torch.int32).reshape(1)
@@ -399,7 +403,8 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
             fin_cnt.add_(done.sum())
             ep_returns.mul_(~done)
             step_t.add_(1)
-            first_t.copy_(torch.where((first_t < 0) & (info["food_collected"] > 0).any(), step_t, first_t))
+            hit = (info["food_collected"] > 0).any() if "food_collected" in info else term.any()
+            first_t.copy_(torch.where((first_t < 0) & hit, step_t, first_t))
             obs.copy_(nobs)
         if learn:
             for _ in range(cfg.updates_per_step):
