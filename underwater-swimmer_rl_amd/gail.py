@@ -53,11 +53,12 @@ class Discriminator(nn.Module):
         self.optimizer.step()
         self.training_step += 1
         with torch.no_grad():
+            el, al = el.detach(), al.detach()
             acc = ((el > 0).float().mean() + (al <= 0).float().mean()) / 2
+            ep, ap = torch.sigmoid(el).mean(), torch.sigmoid(al).mean()
         loss, expert_loss, agent_loss = loss.detach(), expert_loss.detach(), agent_loss.detach()
         return {"discriminator_loss": float(loss), "expert_loss": float(expert_loss), "agent_loss": float(agent_loss),
-                "discriminator_accuracy": float(acc), "expert_prob_mean": float(torch.sigmoid(el).mean()),
-                "agent_prob_mean": float(torch.sigmoid(al).mean())}
+                "discriminator_accuracy": float(acc), "expert_prob_mean": float(ep), "agent_prob_mean": float(ap)}
 
 
 class ExpertBuffer:
