@@ -3,8 +3,8 @@
 max relative state difference after every cycle, and which row / robot carries it."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
 import robot_oracle_lib as rol
 from underwater_swimmer_rl_amd.robot_env import SalpRobotVectorEnv
 
