@@ -93,3 +93,17 @@ def test_robot_abi_symbols_are_exported(lib):
     lib.salp_robot_config_default.argtypes = [ctypes.POINTER(CRobotConfig)]
     assert lib.salp_robot_config_default(ctypes.byref(c)) == 0 and c.struct_size == ctypes.sizeof(CRobotConfig)
     assert (c.width, c.height, c.max_cycles, c.dt, c.nozzle_area) == (900, 700, 500, 0.01, 0.00016)
+
+
+def test_headers_are_plain_c99(tmp_path):
+    """The boundary is a C ABI: both headers must compile as C99 (no C++, no torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "salp_vec.h"\n#include "salp_robot.h"\n'
+                   "int main(void) { salp_config_t c; salp_robot_config_t r; salp_stats_t s; (void)c; (void)r; (void)s; return 0; }\n")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    "-fsyntax-only", str(src)], check=True)
