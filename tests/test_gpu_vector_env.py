@@ -186,3 +186,18 @@ def test_base_num_food_items_poke_like_the_curriculum():
     with pytest.raises(AttributeError):
         sb3.set_attr("food_reward", 1.0)
     env.close(); sb3.close()
+
+
+def test_c_abi_demo_builds_and_runs_from_plain_c(tmp_path):
+    """examples/c_abi_demo.c: the boundary used from C99 with host pointers (no Python, no torch in the process)."""
+    import os, shutil, subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "underwater-swimmer_rl_amd", "csrc")
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.run([gcc, "-std=c99", "-O2", "-Wall", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.c"),
+                    "-o", exe, "-L", libdir, "-lsalp_hip", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
+    assert "env-steps 1228800" in out, out
