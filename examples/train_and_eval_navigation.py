@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Train SAC on the batched simulator, then score the policy with the reference's navigation protocol
+(eval/collect_navigation_data.py restated in underwater_swimmer_rl_amd.navigation_eval): 100 trials from
+(150, 300) to a goal at (650, 300) with a random initial heading; the reference's published policy scores
+success 1.00, 1774 +/- 254 steps, path ratio 1.17 (eval/results/navigation_stats_20251207_165158.json).
+    python examples/train_and_eval_navigation.py --envs 4096 --iters 30000
+Training env: single_food_long_horizon.yaml parameters; learner: that file's agent block, scaled to the batch
+(a larger minibatch and several updates per vector step: 4096 new transitions arrive per step)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import underwater_swimmer_rl_amd as salp
+from underwater_swimmer_rl_amd.navigation_eval import pursuit_policy, run_navigation_trials, summarize
+from underwater_swimmer_rl_amd.sac import SAC, DeviceReplayBuffer, SACConfig, train_sac_graphed
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", default="single_food_long_horizon")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=30000, help="vector env steps")
+    ap.add_argument("--segments", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--updates-per-step", type=int, default=2)
+    args = ap.parse_args()
+    dev = "cuda:0"
+    env = salp.SalpVectorEnv(args.preset, num_envs=args.envs, device=dev, seed=0)
+    cfg = SACConfig.from_preset(args.preset)
+    cfg.batch_size, cfg.updates_per_step, cfg.learning_starts = args.batch, args.updates_per_step, 200
+    cfg.buffer_size = max(cfg.buffer_size, 200 * args.envs)
+    agent = SAC(env.obs_dim, env.act_dim, cfg, device=dev, seed=0,
+                act_low=env.single_action_space.low, act_high=env.single_action_space.high)
+
+    def evaluate(tag):
+        pol = lambda o: agent.act(o, deterministic=True)
+        m = summarize(run_navigation_trials(pol, num_trials=100, device=dev, seed=123))
+        print(json.dumps({"eval": tag, **{k: round(float(v), 4) for k, v in m.items()}}), flush=True)
+        return m
+
+    print(json.dumps({"eval": "scripted pursuit baseline",
+                      **{k: round(float(v), 4) for k, v in summarize(run_navigation_trials(pursuit_policy(), num_trials=100, device=dev, seed=123)).items()}}), flush=True)
+    evaluate("untrained policy")
+    buf = DeviceReplayBuffer(cfg.buffer_size, env.obs_dim, env.act_dim, torch.device(dev))
+    t0 = time.perf_counter()
+    per = args.iters // args.segments
+    for s in range(args.segments):
+        env.clear_stats()
+        m = train_sac_graphed(env, agent, per, buffer=buf)
+        st = env.stats()
+        print(json.dumps({"segment": s + 1, "wall_s": round(time.perf_counter() - t0, 1), "env_steps": st["env_steps"],
+                          "food_per_1000_env_steps": round(1e3 * st["food_collected"] / max(st["env_steps"], 1), 4),
+                          "episodes": st["episodes"], "critic_loss": round(m["critic_loss"], 4), "entropy": round(m["entropy"], 4)}), flush=True)
+        evaluate(f"after segment {s + 1}")
+    env.close()
+
+
+if __name__ == "__main__":
+    main()
