@@ -31,12 +31,18 @@ def main():
     ap.add_argument("--segments", type=int, default=6)
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--updates-per-step", type=int, default=2)
+    ap.add_argument("--auto-alpha", action="store_true", help="learn the entropy coefficient (SB3's default) instead of the YAML's fixed alpha")
+    ap.add_argument("--lr", type=float, default=None)
     args = ap.parse_args()
     dev = "cuda:0"
     env = salp.SalpVectorEnv(args.preset, num_envs=args.envs, device=dev, seed=0)
     cfg = SACConfig.from_preset(args.preset)
     cfg.batch_size, cfg.updates_per_step, cfg.learning_starts = args.batch, args.updates_per_step, 200
     cfg.buffer_size = max(cfg.buffer_size, 200 * args.envs)
+    if args.auto_alpha:
+        cfg.alpha, cfg.target_entropy = None, None
+    if args.lr:
+        cfg.learning_rate = cfg.alpha_lr = args.lr
     agent = SAC(env.obs_dim, env.act_dim, cfg, device=dev, seed=0,
                 act_low=env.single_action_space.low, act_high=env.single_action_space.high)
 
