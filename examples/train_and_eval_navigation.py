@@ -6,10 +6,12 @@ success 1.00, 1774 +/- 254 steps, path ratio 1.17 (eval/results/navigation_stats
     python examples/train_and_eval_navigation.py --envs 4096 --iters 30000
 Training env: single_food_long_horizon.yaml parameters; learner: that file's agent block, scaled to the batch
 (a larger minibatch and several updates per vector step: 4096 new transitions arrive per step).
-Measured on one MI355X (--iters 120000 --segments 8: 4.9e8 env-steps and 2.4e5 updates in 302 s, 1.6e6 env-steps/s
-including learning and the eight evaluations): the policy's navigation success moves between 0 and 0.57 from
-segment to segment — it learns to reach the goal but this learner setting (update-to-data ratio 1/2048, fixed
-alpha 0.2) is not stable; no tuning was done.  The scripted pursuit baseline scores 0.67 on the same trials."""
+Measured on one MI355X: the YAML's fixed alpha (--iters 120000 --segments 8: 4.9e8 env-steps and 2.4e5 updates in
+302 s, 1.6e6 env-steps/s including learning and the evaluations) moves between 0 and 0.57 navigation success from
+evaluation to evaluation; --auto-alpha --batch 4096 --updates-per-step 4 (--iters 180000 --segments 9, 1044 s)
+reaches 0.78 (1906 steps, path ratio 1.24) after 930 s and loses it again in the next segment.  The policy learns to
+reach the goal, but this untuned learner is not stable; the scripted pursuit baseline scores 0.67 on the same trials
+and the reference's published policy 1.00."""
 import argparse
 import json
 import os
