@@ -6,7 +6,9 @@ success 1.00, 1774 +/- 254 steps, path ratio 1.17 (eval/results/navigation_stats
     python examples/train_and_eval_navigation.py --envs 4096 --iters 30000
 Training env: single_food_long_horizon.yaml parameters; learner: that file's agent block, scaled to the batch
 (a larger minibatch and several updates per vector step: 4096 new transitions arrive per step).
-Measured on one MI355X (1.6e6 env-steps/s including learning and the evaluations):
+Measured on one MI355X (1.6e6 env-steps/s including learning and the evaluations), with trials still ending at the
+first `done` (before navigation_eval ignored it as the reference's loop does; the pursuit baseline scored 0.67 under that
+rule and scores 0.99 now):
   * the YAML's learner as is (fixed alpha 0.2; --iters 120000 --segments 8, 302 s): navigation success moves between
     0 and 0.57 from evaluation to evaluation; learned alpha with batch 4096 x 4 updates per step: up to 0.78, equally
     unstable (Q-values in the hundreds);

@@ -100,7 +100,10 @@ typedef struct salp_config {
   int32_t inhale_duration;         /* 120 */
   int32_t exhale_duration;         /* 150 */
   int32_t rest_duration;           /* 60 (enters only through the 330-step modulus, legacy:161) */
-  int32_t reserved0;
+  int32_t no_autoreset;            /* 0: an env that terminates or truncates starts its next episode in the same step
+                                    * (VectorEnv convention).  1: it is NOT reset, exactly like the reference's single env
+                                    * when its caller ignores `done` and keeps stepping (eval/collect_navigation_data.py:
+                                    * 97-114 rides through wall contacts this way); flags are still reported each step. */
 } salp_config_t;
 
 /* Rows of the state snapshot exchanged by salp_vec_get_state / salp_vec_set_state.

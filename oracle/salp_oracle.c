@@ -524,7 +524,7 @@ static int rollout_impl(salp_oracle_t* h, const float* act, const double* act64,
         info[row * SALP_INFO_COLS + SALP_INFO_STEPS_SINCE_FOOD] = e->steps_since_food;
         info[row * SALP_INFO_COLS + SALP_INFO_COLLISION] = coll;
       }
-      if (term || trunc) {
+      if ((term || trunc) && !h->cfg.no_autoreset) {   /* no_autoreset: the caller ignores `done`, as a hand loop may */
         if (final_obs) observe(h, e, final_obs + row * od);
         reset_env(h, i, e);
       }

@@ -136,7 +136,7 @@ def run_case(name, params, actions, seed, base=0, inject=None, notes="", food_sc
                 ESCAPES[0] += 1
             rew[t, i], term[t, i], trunc[t, i] = rw, te, tr
             info[t, i] = (inf["food_collected"], inf["steps_since_food"], int(inf["collision"]))
-            if te or tr:
+            if (te or tr) and not cfg.no_autoreset:      # no_autoreset: a hand loop that ignores `done`
                 fin[t, i] = o
                 o = r.reset()
                 r.episode_length = 0
@@ -144,6 +144,8 @@ def run_case(name, params, actions, seed, base=0, inject=None, notes="", food_sc
             obs[t, i] = o
     end_f64, end_i32 = snapshot(envs, F)
     meta = dict(cfg.env_kwargs(), seed=seed, env_index_base=base, case=name, notes=notes)
+    if cfg.no_autoreset:
+        meta["no_autoreset"] = True
     out = dict(cfg_json=np.array(json.dumps(meta)), actions=actions, reset_obs=reset_obs, obs=obs, final_obs=fin,
                reward=rew, terminated=term, truncated=trunc, info=info, end_f64=end_f64, end_i32=end_i32)
     if inj_f64 is not None:
@@ -261,6 +263,20 @@ def main(only=None):
     run_case("curriculum_random", dict(preset="sac_gail", num_food_items=6, max_steps_without_food=45,
                                        random_food_count=True),
              uniform_actions(480, 5, 1, 27), seed=28, food_schedule=sch, notes="poke + randint(1, base)")
+
+    # --- callers that ignore `done` (eval/collect_navigation_data.py:97-114): no reset after a wall contact or a
+    #     time-out; the swimmers ride along / bounce off the walls and keep being stepped
+    def rush2(f64, i32):
+        n = f64.shape[1]
+        f64[F_X] = 640.0 + 4.0 * np.arange(n)
+        f64[F_Y] = 280.0 + 25.0 * np.arange(n)
+        f64[F_VX] = 1.5
+        f64[F_VY] = 0.3 * np.arange(n)
+        f64[F_THETA] = 0.15 * np.arange(n) - 0.5
+    ev = run_case("no_autoreset", dict(preset="single_food", max_steps_without_food=300, no_autoreset=True),
+                  uniform_actions(700, 8, 1, 29), seed=30, inject=rush2,
+                  notes="done ignored: wall contacts and truncation without reset")
+    assert ev["terminated"] >= 5 and ev["truncated"] >= 5
 
     # --- env_index_base: the same global envs from a shard
     run_case("shard_base_1000", dict(preset="single_food_long_horizon"), uniform_actions(128, 4, 1, 23), seed=1001,

@@ -20,7 +20,7 @@ def fixture_names():
 def load_fixture(name):
     z = np.load(os.path.join(GOLDEN_DIR, f"ref_{name}.npz"), allow_pickle=False)
     meta = json.loads(str(z["cfg_json"]))
-    cfg = pkg.SalpSnakeConfig(**{k: meta[k] for k in KW})
+    cfg = pkg.SalpSnakeConfig(**{k: meta[k] for k in KW}, no_autoreset=bool(meta.get("no_autoreset", False)))
     return z, meta, cfg
 
 

@@ -48,7 +48,7 @@ class CConfig(ctypes.Structure):
         ("inhale_duration", ctypes.c_int32),
         ("exhale_duration", ctypes.c_int32),
         ("rest_duration", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("no_autoreset", ctypes.c_int32),
     ]
 
 
@@ -81,6 +81,8 @@ class SalpSnakeConfig:
     inhale_duration: int = 120
     exhale_duration: int = 150
     rest_duration: int = 60
+    # not a reference kwarg: keep finished envs running instead of resetting them (salp_config_t.no_autoreset)
+    no_autoreset: bool = False
 
     def __post_init__(self):
         # snake:36 base_num_food_items = max(0, num_food_items)
@@ -104,7 +106,7 @@ class SalpSnakeConfig:
         c = CConfig()
         c.struct_size = ctypes.sizeof(CConfig)
         for name, _ in CConfig._fields_:
-            if name in ("struct_size", "reserved0"):
+            if name in ("struct_size",):
                 continue
             v = getattr(self, name)
             setattr(c, name, int(v) if isinstance(v, (bool, int)) else float(v))

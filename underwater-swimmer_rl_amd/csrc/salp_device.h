@@ -51,6 +51,7 @@ struct DevParams {
   int F, K;                 // food slots (num_food_items at creation), max_observed_food
   int F_base;               // base_num_food_items: foods of the next episodes, 0..F (snake:36, :144-148)
   int forced, random_food_count, respawn;
+  int autoreset;            // 0: finished envs keep running (salp_config_t.no_autoreset)
   uint32_t seed_lo, seed_hi;
   uint64_t env_base;        // global index of local env 0
   int64_t n;                // envs in this handle

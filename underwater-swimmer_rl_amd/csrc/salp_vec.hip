@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
       if (active && io.stats) {
         if (o.collected) atomicAdd(&blk_stats[ST_FOOD], 1ull);
         if (o.collision) atomicAdd(&blk_stats[ST_COLL], 1ull);
-        if (done) {
+        if (done && P.autoreset) {
           atomicAdd(&blk_stats[ST_EPISODES], 1ull);
           atomicAdd(&blk_stats[o.terminated ? ST_TERM : ST_TRUNC], 1ull);
           atomicAdd(&blk_stats[ST_EPLEN], (unsigned long long)e.eplen);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
       }
 #pragma unroll 1
       for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && done) {
+        if (pass == 1 && done && P.autoreset) {
           if (!FULL && io.final_obs && active) {
             float fo[12 + 4 * KMAX];
             if constexpr (LDSF) {   // the terminal observation sees the respawned food (pass 0)
@@ -538,6 +538,7 @@ DevParams make_params(const salp_config_t& c, int64_t n, int64_t pitch, uint64_t
   P.F_base = c.num_food_items;
   P.forced = c.forced_breathing != 0; P.random_food_count = c.random_food_count != 0;
   P.respawn = c.respawn_food != 0;
+  P.autoreset = c.no_autoreset == 0;
   P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
   P.env_base = (uint64_t)base; P.n = n; P.pitch = pitch;
   return P;

@@ -5,7 +5,8 @@ Restates the protocol and metrics of the reference's eval/collect_navigation_dat
   * per trial: reset, then overwrite pose (start position, zero velocity, heading ~ U(-pi, pi), zero
     angular velocity), place the single food at the goal, zero steps_since_food (:76-89) — here through
     `set_state`;
-  * roll the policy until the swimmer is within `goal_radius` (50 px) of the goal or `max_steps` (:97-114);
+  * roll the policy until the swimmer is within `goal_radius` (50 px) of the goal or `max_steps` (:97-114); the
+    reference's loop ignores `terminated` / `truncated`, so wall contacts do not end a trial (`no_autoreset`);
   * metrics (:117-196): path length (+ final distance to the goal), success (final distance < 50),
     path ratio, straightness, mean lateral deviation from the start-goal line, bounding-box area and
     area ratio, x / y range.  (The reference's optional spline-smoothed path ratio is not restated.)
@@ -25,7 +26,10 @@ from .vector_env import SalpVectorEnv
 
 
 def navigation_config(**overrides):
-    params = dict(num_food_items=1, forced_breathing=True, respawn_food=False, max_steps_without_food=3000)
+    # no_autoreset: the reference's trial loop ignores `done` (:97-114) — a swimmer that touches a wall is clamped,
+    # bounces and swims on; nothing is reset until the trial ends
+    params = dict(num_food_items=1, forced_breathing=True, respawn_food=False, max_steps_without_food=3000,
+                  no_autoreset=True)
     params.update(overrides)
     return SalpSnakeConfig(**params)   # the reference builds SalpSnakeEnv with its class defaults here
 
@@ -71,16 +75,14 @@ def run_navigation_trials(policy: Callable, num_trials: int = 100, start_pos=(15
     for t in range(max_steps):
         act = policy(obs)
         nobs, rew, term, trunc, info = env.step(act)
-        # position of the step just taken: from the terminal observation where the env finished
-        # (same-step autoreset), else from the returned one (x / W, y / H in columns 0, 1)
-        done = term | trunc
-        o = torch.where(done[:, None], info["final_observation"], nobs)
-        p = torch.stack([o[:, 0] * W, o[:, 1] * H], dim=1)
+        # position of the step just taken (x / W, y / H in columns 0, 1); `terminated` / `truncated` are ignored as in
+        # the reference's loop, the env runs on (no_autoreset)
+        p = torch.stack([nobs[:, 0] * W, nobs[:, 1] * H], dim=1)
         pos[t + 1] = torch.where(running[:, None], p, pos[t])
         steps += running.to(torch.int32)
         collided |= running & (info["collision"] > 0)
         reached = (pos[t + 1] - goal).norm(dim=1) < goal_radius
-        running = running & ~reached & ~done
+        running = running & ~reached
         obs = nobs.clone()
         T = t + 1
         if not bool(running.any()):
