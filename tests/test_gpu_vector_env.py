@@ -173,6 +173,7 @@ def test_base_num_food_items_poke_like_the_curriculum():
     env = pkg.SalpVectorEnv("sac_gail", num_envs=300, device="cuda:0", seed=4, num_food_items=6, max_steps_without_food=30)
     obs, _ = env.reset()
     assert env.base_num_food_items == 6 and float(obs[:, 22].min()) == pytest.approx(0.6)
+    assert (env.num_food_items == 6).all()             # what continuous_trainer.py:380 reads, per env
     env.base_num_food_items = 2
     with pytest.raises(Exception):
         env.base_num_food_items = 7                    # more than the slots the env was created with
@@ -180,6 +181,7 @@ def test_base_num_food_items_poke_like_the_curriculum():
     for _ in range(40):                                # every env truncates at step 31 and resets with 2 foods
         obs, *_ = env.step(act)
     assert float(obs[:, 22].max()) <= 0.2 + 1e-6
+    assert (env.num_food_items == 2).all()
     sb3 = pkg.SalpSB3VecEnv("sac_gail", num_envs=4, device=0, num_food_items=5)
     sb3.set_attr("base_num_food_items", 3)
     assert sb3.get_attr("base_num_food_items") == [3, 3, 3, 3]

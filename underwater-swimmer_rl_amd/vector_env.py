@@ -309,6 +309,16 @@ class SalpVectorEnv:
         return np.stack([f[_capi.F_FOOD0:_capi.F_FOOD0 + F].T, f[_capi.F_FOOD0 + F:_capi.F_FOOD0 + 2 * F].T], axis=2)
 
     @property
+    def num_food_items(self):
+        """Per env, the number of foods of its CURRENT episode (what continuous_trainer.py:380 reads from the single
+        env: `base_num_food_items`, or the episode's draw with random_food_count).  Recovered from the state: live
+        foods, plus the captured ones when foods do not respawn."""
+        f64, i32 = self.get_state()
+        F = self.cfg.num_food_items
+        live = (~np.isnan(f64[_capi.F_FOOD0:_capi.F_FOOD0 + F])).sum(axis=0)
+        return live if self.cfg.respawn_food else live + i32[_capi.I_FOOD_COLLECTED]
+
+    @property
     def base_num_food_items(self) -> int:
         """The attribute the reference's curriculum writes (continuous_trainer.py:409-411; snake:36): foods
         placed at every later reset, 0..cfg.num_food_items (the slots the env was created with)."""
