@@ -76,3 +76,31 @@ def test_bench_roofline_accounting():
     assert bench.algorithmic_bytes_per_env_step(cfg, 1) == 218.0              # SURVEY.md §8d step-per-launch
     assert abs(bench.algorithmic_bytes_per_env_step(cfg, 5000) - 106.0224) < 1e-9
     assert bench.algorithmic_bytes_per_env_step(pkg.load_env_config("sac_gail"), 1) == 394.0
+
+
+def test_adaptive_food_curriculum_follows_the_reference_rule():
+    """continuous_trainer.py:375-415: window of 10 episodes, > 0.6 removes a food, < 0.25 adds one, within [2, 12],
+    window cleared after a change; the change is the base_num_food_items write."""
+    from underwater_swimmer_rl_amd.curriculum import AdaptiveFoodCurriculum
+
+    class Env:
+        base_num_food_items = 5
+
+    env = Env()
+    cur = AdaptiveFoodCurriculum(env)
+    for _ in range(9):
+        assert not cur.record_episode(5, 5)            # window not full yet
+    assert cur.record_episode(5, 5) and env.base_num_food_items == 4 and cur.recent_food_collection_rates == []
+    for _ in range(9):
+        assert not cur.record_episode(0, 4)
+    assert cur.record_episode(0, 4) and env.base_num_food_items == 5
+    for _ in range(30):                                # middling performance: nothing changes, the window slides
+        assert not cur.record_episode(2, 5)
+    assert len(cur.recent_food_collection_rates) == 10 and env.base_num_food_items == 5
+    env.base_num_food_items = 2
+    low = AdaptiveFoodCurriculum(env)
+    assert low.record_finished([2] * 25, [2] * 25) == 0 and env.base_num_food_items == 2      # floor
+    env.base_num_food_items = 12
+    high = AdaptiveFoodCurriculum(env)
+    assert high.record_finished([0] * 25, [12] * 25) == 0 and env.base_num_food_items == 12   # ceiling
+    assert cur.changes == [4, 5]
