@@ -114,8 +114,13 @@ def main():
         raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # SALP_BENCH_REHEARSAL=1 (one-GPU boxes only): ranks share the visible GPUs (local_rank modulo their number) and
+    # talk over gloo, so that the multi-process code path — sharding by rank, barriers, the max-over-ranks timing,
+    # rank-0 reporting — can be run where RCCL cannot put two ranks on one device.  Never used by a real run.
+    rehearsal = os.environ.get("SALP_BENCH_REHEARSAL") == "1" and world > 1
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     # SALP_BENCH_FORCE_SHARDED=1 runs the sharded (RCCL) code path at world size 1 — a rehearsal of the
     # multi-GPU path on a one-GPU box; the reported numbers are then those of that path.
     force_sharded = world == 1 and os.environ.get("SALP_BENCH_FORCE_SHARDED") == "1"
@@ -125,6 +130,8 @@ def main():
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")   # RCCL's stream ahead of the rollout launches in the dispatcher
         if force_sharded:
             dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+        elif rehearsal:
+            dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=device)
 
@@ -133,11 +140,11 @@ def main():
 
     if world > 1 or force_sharded:
         from underwater_swimmer_rl_amd.sharded import ShardedSalpVectorEnv
-        senv = ShardedSalpVectorEnv(cfg, n * world, device=f"cuda:{local_rank}", seed=0)
+        senv = ShardedSalpVectorEnv(cfg, n * world, device=f"cuda:{dev_index}", seed=0)
         env = senv.engine
     else:
         senv = None
-        env = SalpVectorEnv(cfg, n, device=f"cuda:{local_rank}", seed=0, env_index_base=0)
+        env = SalpVectorEnv(cfg, n, device=f"cuda:{dev_index}", seed=0, env_index_base=0)
 
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
