@@ -55,6 +55,9 @@ def main():
                 s.record(); launch(name); e.record(); e.synchronize()
                 times[name].append(s.elapsed_time(e))
     out = {name: {"median_ms": statistics.median(t), "min_ms": min(t), "max_ms": max(t), "n": len(t)} for name, t in times.items()}
+    if os.environ.get("AB_DUMP") == "1":   # every launch time in order (e.g. with AB_WARM=0: the phase mix desynchronising)
+        for name, t in times.items():
+            out[name]["all_ms"] = [round(x, 4) for x in t]
     print(json.dumps(out, indent=1))
 
 if __name__ == "__main__":

@@ -14,8 +14,14 @@ DEPS = [SRC, SRC_ROBOT, os.path.join(HERE, "salp_device.h"), os.path.join(HERE, 
         os.path.join(HERE, "..", "..", "include", "salp_robot.h")]
 OUT = os.path.join(HERE, "libsalp_hip.so")
 # -ffp-contract=off: the fp64 state update must round exactly where the reference rounds
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# Per-source flags.  salp_vec.hip: machine LICM hoists every fp64 literal of the step loop (each one an
+# s_mov pair or a v_mov pair) into registers that then live across the whole loop — ~45 VGPRs of polynomial
+# coefficients and >100 SGPRs, the latter spilled to VGPR lanes and read back with v_readlane in the loop.
+# Without it the one-food kernel needs 92 VGPRs / 76 SGPRs and no scratch (was 128 / 106 + 38 spilled + 20 B
+# scratch), the 12-food kernel 107 VGPRs (was 160).  Measured: profiles/r02/ab_notes.md.
+SRC_FLAGS = {SRC: ["-mllvm", "-disable-machine-licm"], SRC_ROBOT: []}
 
 
 def hipcc() -> str:
@@ -25,23 +31,38 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build(force: bool = False, verbose: bool = False, out: str = OUT, defines=()) -> str:
-    """`out`/`defines` build experiment variants (profiles/ab_bench.py); the product is the default."""
+def build(force: bool = False, verbose: bool = False, out: str = OUT, defines=(), extra_flags=()) -> str:
+    """`out`/`defines`/`extra_flags` build experiment variants (profiles/ab_bench.py); the product is the default."""
     if not force and os.path.isfile(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
         return out
-    cmd = [hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out, SRC, SRC_ROBOT]
+    objs, procs = [], []
+    for src in (SRC, SRC_ROBOT):      # one compile per source (different flags), in parallel, then link
+        obj = out + "." + os.path.splitext(os.path.basename(src))[0] + ".o"
+        cmd = [hipcc()] + FLAGS + SRC_FLAGS[src] + list(extra_flags) + [f"-D{d}" for d in defines] + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, cwd=HERE)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=HERE)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True, cwd=HERE)
+    for o in objs:
+        os.remove(o)
     return out
 
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if a != "--force"]
-    out, defs = OUT, []
+    out, defs, extra = OUT, [], []
     for a in args:
         if a.startswith("--out="):
             out = os.path.abspath(a[6:])
         elif a.startswith("-D"):
             defs.append(a[2:])
-    print(build(force="--force" in sys.argv, verbose=True, out=out, defines=defs))
+        elif a.startswith("--flag="):       # e.g. --flag=-mllvm --flag=-disable-machine-licm
+            extra.append(a[7:])
+    print(build(force="--force" in sys.argv, verbose=True, out=out, defines=defs, extra_flags=extra))

@@ -189,7 +189,12 @@ __device__ __forceinline__ void store_env(const Env<FMAX>& e, const DevState& S,
 
 // One Philox block of this env's draw stream (include/salp_vec.h "Randomness").
 __device__ __forceinline__ U4 next_block(EnvCore& e, const DevParams& P, uint64_t genv) {
-  U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), e.rng, 0u, P.seed_lo, P.seed_hi);
+  // The key is made opaque here: otherwise the 18 round keys (seed + r * Weyl constant) are hoisted out of the
+  // step loop as loop invariants, spilled to VGPR lanes and read back with v_readlane on every use — two
+  // scalar adds per round in place are cheaper.
+  uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
+  asm volatile("" : "+s"(k0), "+s"(k1));
+  U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), e.rng, 0u, k0, k1);
   e.rng += 1u;
   return w;
 }
@@ -307,24 +312,25 @@ __device__ __forceinline__ void place_food(Env<FMAX>& e, const DevParams& P, uin
 
 // legacy:95-117 reset + snake:133-149 (pose, breathing, counters, episode food count); the food
 // itself is placed by place_food(e, ..., todo = return value, limit = 100).
+// F_base: base_num_food_items of this launch (the one constant a caller may change between launches).
 template <bool STD>
-__device__ __forceinline__ int reset_core(EnvCore& e, const DevParams& P, uint64_t genv) {
+__device__ __forceinline__ int reset_core(EnvCore& e, const DevParams& P, uint64_t genv, int F_base) {
   e.x = CV(half_W); e.y = CV(half_H); e.vx = 0.0; e.vy = 0.0; e.th = 0.0; e.om = 0.0;
   e.noz = 0.0; e.water = 0.0; e.epret = 0.0;
   e.packed = pack_breath(0, 0, bw_dur(e.packed), 7);
   e.ssf = 0; e.fc = 0; e.eplen = 0;
-  int nf = P.F_base;
+  int nf = F_base;
   if (P.random_food_count) {  // snake:146 random.randint(1, max(1, base))
     const U4 w = next_block(e, P, genv);
-    const uint32_t n = (uint32_t)(P.F_base > 1 ? P.F_base : 1);
+    const uint32_t n = (uint32_t)(F_base > 1 ? F_base : 1);
     nf = 1 + (int)(((uint64_t)w.x * (uint64_t)n) >> 32);
     if (nf > P.F) nf = P.F;
   }
   return nf;
 }
 template <int FMAX, bool STD>
-__device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint64_t genv) {
-  const int nf = reset_core<STD>(e, P, genv);
+__device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint64_t genv, int F_base) {
+  const int nf = reset_core<STD>(e, P, genv, F_base);
 #pragma unroll
   for (int k = 0; k < FMAX; ++k) { e.fx[k] = __builtin_nan(""); e.fy[k] = __builtin_nan(""); }
   return nf;

@@ -27,94 +27,137 @@ struct FoodLds {
 };
 
 // Result of one pass over the slots.
+//
+// Sort keys.  The K nearest are kept by a sorted insertion on PACKED keys: the fp64 squared distance with the
+// low 4 bits of its mantissa replaced by the slot number (slots are 0..15).  All keys of an env are then
+// distinct, so the compare-exchange of a chain stage is just v_min_f64 / v_max_f64 (no index selects), a
+// smaller key is a nearer food, and squared distances that agree to within 16 ulp of fp64 — which includes
+// exact ties — order by slot, like the reference's stable sort on sqrt(d2) (snake:382), which itself cannot
+// tell squared distances ~2 ulp apart.  An empty slot's key is kDeadKey | slot (finite, above any distance).
+// Everything that leaves the selection (offsets, distance) is recomputed from the slot's exact position.
 template <int KMAX>
 struct FoodScan {
-  double t[KMAX];    // squared distances of the K nearest live foods, ascending (+inf: none)
-  int idx[KMAX];     // their slots (-1: none); equal distances keep slot order
-  float bx[KMAX], by[KMAX], bd[KMAX];   // offsets and distance of those foods in fp32 (filled by resolve())
+  double key[KMAX];  // packed keys of the K nearest live foods, ascending
+  int idx[KMAX];     // their slots (-1: none)                                  (filled by resolve())
+  float bx[KMAX], by[KMAX], bd[KMAX];   // offsets and distance of those foods in fp32  (filled by resolve())
   float dsum;        // sum of distances over ALL live foods
-  int cnt;           // live foods
 };
+__device__ __forceinline__ double dead_key() { return __builtin_bit_cast(double, 0x7FEFFFFFFFFFFFF0ull); }
+__device__ __forceinline__ double pack_key(double d2, int k) {
+  uint2 u = __builtin_bit_cast(uint2, d2);
+  u.x = (u.x & ~15u) | (uint32_t)k;                                 // one v_and_or_b32 on the low dword
+  return __builtin_bit_cast(double, u);
+}
+// v_min_f64 / v_max_f64 written as instructions: llvm.minnum on a bit-cast value gets a canonicalising
+// v_max_f64 v, v, v in front of it.  Packed keys are never NaN; for min_key(d2, dead) the kernel runs in IEEE
+// mode, where the minimum of a quiet NaN (an empty slot) and a number is the number.
+__device__ __forceinline__ double min_key(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double min_key_s(double a, double b_uniform) {   // b in an SGPR pair
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
+  return r;
+}
+__device__ __forceinline__ double max_key(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ int key_slot(double key) { return (int)(__builtin_bit_cast(unsigned long long, key) & 15ull); }
+__device__ __forceinline__ bool key_found(double key) { return key < 1.0e300; }
 
-// One pass over slots 0..F-1 around (x, y).  CAPTURE: also the reference's capture test with radius^2 =
-// cr2 — the first slot inside wins, is reported in hit_k and is treated as already gone by everything
-// else in the pass (the reward's nearest food and the observation are taken after it is cleared,
-// snake:171-189, 301).
-template <int KMAX, bool CAPTURE>
+// One pass over the slots around (x, y): the K smallest packed keys and the distance sum.  The pass runs over
+// ceil(F / 4) * 4 slots in fully unrolled groups of four (the kernel keeps slots F..FMAX-1 empty, FMAX being a
+// multiple of four): an empty slot costs what a live one does and changes nothing.
+//   CAPTURE = false (the common step): nothing else.  The caller decides from key[0] whether any food can be
+//     inside the capture radius at all and only then runs the CAPTURE pass.
+//   CAPTURE = true: also the reference's capture test with radius^2 = cr2 — the first slot inside wins, is
+//     reported in hit_k and is treated as already gone by everything else in the pass (the reward's nearest
+//     food and the observation are taken after it is cleared, snake:171-189, 301).
+//   COUNT: also the number of live foods in `cnt` (carried in a register between food-set changes).
+template <int KMAX, bool CAPTURE, bool COUNT>
 __device__ __forceinline__ void scan_foods(const FoodLds& f, int F, double x, double y, double cr2, FoodScan<KMAX>& q,
-                                           bool& collected, int& hit_k) {
-  const double inf = __builtin_inf();
+                                           bool& collected, int& hit_k, int& cnt) {
+  const double dead = dead_key();
 #pragma unroll
-  for (int s = 0; s < KMAX; ++s) { q.t[s] = inf; q.idx[s] = -1; }
+  for (int s = 0; s < KMAX; ++s) q.key[s] = dead;
   float dsum = 0.f;
-  int cnt = 0;
+  int n = 0;
   collected = false;
   hit_k = 0;
-#ifndef SALP_SCAN_UNROLL
-#define SALP_SCAN_UNROLL 4
-#endif
-#pragma unroll SALP_SCAN_UNROLL
-  for (int k = 0; k < F; ++k) {
-    double fx, fy;
-    f.get(k, fx, fy);
-    const double dx = fx - x, dy = fy - y;
-    const double d2 = dx * dx + dy * dy;
-    bool live = !is_none(fx);
-    if (CAPTURE) {
-      const bool hit = !collected && (d2 < cr2);   // NaN (empty slot) never hits
-      collected = collected || hit;
-      hit_k = hit ? k : hit_k;
-      live = live && !hit;
-    }
-    cnt += live ? 1 : 0;
-    dsum += live ? __builtin_amdgcn_sqrtf((float)d2) : 0.f;
-    const double v = live ? d2 : inf;
-    // sorted insertion as a chain of compare-exchanges (v_min_f64 / v_max_f64 + two selects for the slot):
-    // the newcomer only moves ahead of strictly larger keys, so equal distances keep their slot order
-    double cv = v;
-    int ck = k;
+#pragma unroll 1
+  for (int k0 = 0; k0 < F; k0 += 4) {
+    double fx[4], fy[4];
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) {
-      const bool lt = cv < q.t[s];
-      const double lo = __builtin_fmin(cv, q.t[s]), hi = __builtin_fmax(cv, q.t[s]);
-      const int ilo = lt ? ck : q.idx[s], ihi = lt ? q.idx[s] : ck;
-      q.t[s] = lo; q.idx[s] = ilo;
-      cv = hi; ck = ihi;
+    for (int j = 0; j < 4; ++j) f.get(k0 + j, fx[j], fy[j]);   // the four LDS reads in flight together
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j;
+      const double dx = fx[j] - x, dy = fy[j] - y;
+      double d2 = dx * dx + dy * dy;                 // NaN for an empty slot
+      if (CAPTURE) {
+        const bool hit = !collected && (d2 < cr2);   // NaN never hits
+        collected = collected || hit;
+        hit_k = hit ? k : hit_k;
+        d2 = hit ? __builtin_nan("") : d2;
+      }
+      if (COUNT) n += (d2 == d2) ? 1 : 0;
+      dsum += __builtin_fmaxf(__builtin_amdgcn_sqrtf((float)d2), 0.f);   // maxnum: NaN (empty) adds 0
+      // sorted insertion as a chain of compare-exchanges on distinct keys; v_min_f64 turns NaN into the dead key
+      double cv = pack_key(min_key_s(d2, dead), k);
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) {
+        const double lo = min_key(cv, q.key[s]);
+        if (s + 1 < KMAX) cv = max_key(cv, q.key[s]);
+        q.key[s] = lo;
+      }
     }
   }
   q.dsum = dsum;
-  q.cnt = cnt;
+  if (COUNT) cnt = n;
 }
 
-// fp32 geometry of the first K selected foods (what the reward and the observation consume).
+// fp32 geometry of the first K selected foods (what the reward and the observation consume), from the exact
+// positions of the selected slots.
 template <int KMAX>
 __device__ __forceinline__ void resolve(const FoodLds& f, int K, double x, double y, FoodScan<KMAX>& q) {
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) {
-    q.bx[s] = 0.f; q.by[s] = 0.f; q.bd[s] = 0.f;
+    q.bx[s] = 0.f; q.by[s] = 0.f; q.bd[s] = 0.f; q.idx[s] = -1;
     if (s < K) {
       double fx, fy;
-      f.get(q.idx[s] < 0 ? 0 : q.idx[s], fx, fy);
-      const bool found = q.idx[s] >= 0;
-      q.bx[s] = found ? (float)(fx - x) : 0.f;
-      q.by[s] = found ? (float)(fy - y) : 0.f;
-      q.bd[s] = found ? __builtin_amdgcn_sqrtf((float)q.t[s]) : 0.f;
+      const int k = key_slot(q.key[s]);
+      f.get(k, fx, fy);
+      const bool found = key_found(q.key[s]);
+      const double dx = fx - x, dy = fy - y;
+      q.idx[s] = found ? k : -1;
+      q.bx[s] = found ? (float)dx : 0.f;
+      q.by[s] = found ? (float)dy : 0.f;
+      q.bd[s] = found ? __builtin_amdgcn_sqrtf((float)(dx * dx + dy * dy)) : 0.f;
     }
   }
 }
 
 // One reference step of a multi-food env (the LDS counterpart of step_env<FMAX>): same order of
-// operations, the food loop being one scan.  Leaves the selection of the post-step food set in q.
+// operations, the food loop being one scan.  Leaves the selection of the post-step food set in q and keeps
+// `nlive` (live foods of this env) current.
 template <int KMAX, bool FORCED, bool STD>
 __device__ __forceinline__ StepOut step_env_lds(EnvCore& e, const FoodLds& f, const DevParams& P, uint64_t genv, float a0, float a1,
-                                                int K, FoodScan<KMAX>& q) {
+                                                int K, FoodScan<KMAX>& q, int& nlive) {
   const double r = step_head<FORCED, STD>(e, P, genv, a0, a1);
   StepOut o;
   o.rmax = r;
   const double cr = r + CV(food_radius);
-  int hit_k;
-  scan_foods<KMAX, true>(f, P.F, e.x, e.y, cr * cr, q, o.collected, hit_k);
-  if (__any(o.collected)) {
+  const double cr2 = cr * cr;
+  int hit_k, cnt_;
+  scan_foods<KMAX, false, false>(f, P.F, e.x, e.y, 0.0, q, o.collected, hit_k, cnt_);
+  // A capture needs a live food with d2 < cr2, and then the smallest key is below cr2 too (the packing moves a
+  // key by < 16 ulp: the margin).  Only then — a few percent of the wavefront-steps — run the exact test.
+  if (__any(q.key[0] < cr2 * 1.00000000001)) {
+    scan_foods<KMAX, true, true>(f, P.F, e.x, e.y, cr2, q, o.collected, hit_k, nlive);
     if (o.collected) f.clear(hit_k);
   }
   resolve<KMAX>(f, K > 0 ? K : 1, e.x, e.y, q);   // the reward needs the nearest even when K = 0
@@ -132,14 +175,14 @@ __device__ __forceinline__ StepOut step_env_lds(EnvCore& e, const FoodLds& f, co
     rew += o.rel_valid ? al : 0.0;
   }
   rew += P.time_penalty;
-  step_tail(e, P, o, rew, q.cnt > 0);
+  step_tail(e, P, o, rew, nlive > 0);
   return o;
 }
 
 // The observation row from a scan of the CURRENT food set around the CURRENT pose.
 template <int KMAX, bool STD>
 __device__ __forceinline__ void observe_lds(const EnvCore& e, const DevParams& P, double rmax, int K, const FoodScan<KMAX>& q,
-                                            bool have_rel, float rel0, float (&o)[12 + 4 * KMAX]) {
+                                            int nlive, bool have_rel, float rel0, float (&o)[12 + 4 * KMAX]) {
   o[0] = (float)e.x * (float)CV(inv_W);
   o[1] = (float)e.y * (float)CV(inv_H);
   o[2] = (float)e.vx * 0.2f;
@@ -169,9 +212,9 @@ __device__ __forceinline__ void observe_lds(const EnvCore& e, const DevParams& P
     }
     o[10 + 4 * s + 0] = v0; o[10 + 4 * s + 1] = v1; o[10 + 4 * s + 2] = v2; o[10 + 4 * s + 3] = v3;
   }
-  const float fcnt = (float)q.cnt;
+  const float fcnt = (float)nlive;
   const float s0 = fminf(fcnt * 0.1f, 1.0f);
-  const float s1 = (q.cnt > 0) ? (q.dsum * __builtin_amdgcn_rcpf(fcnt)) * CV(inv_diag) : 1.0f;
+  const float s1 = (nlive > 0) ? (q.dsum * __builtin_amdgcn_rcpf(fcnt)) * CV(inv_diag) : 1.0f;
   if (KMAX == 3) {
     o[22] = s0; o[23] = s1;
   } else {

@@ -60,6 +60,17 @@ struct IOPtrs {
   int64_t global_step;    // step index of t = 0 (device-generated actions)
 };
 
+// Device-memory copy of the launch constants for the RARE paths of the rollout kernel (respawn / autoreset
+// region, exact capture pass, state write-back).  Everything the per-step path needs arrives by value in
+// `P` (scalar registers); what only the rare paths read is fetched from this block when they run, so it
+// does not occupy scalar registers across the step loop (the by-value copy alone left ~125 SGPRs spilled
+// to VGPR lanes, ~110 v_readlane / v_writelane per step in the 12-food kernel).  Immutable after create;
+// base_num_food_items, the one field a caller may change between launches, is always taken from `P`.
+struct ColdBlock {
+  DevParams P;
+  DevState S;
+};
+
 // FULL = the common rollout signature (act, obs, reward, terminated, truncated all present; no
 // final_obs / info): no per-step null tests.
 // RAGGED = false: every wavefront of the launch is either full (64 envs) or empty, so no store is
@@ -71,7 +82,7 @@ struct IOPtrs {
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
 template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 12 ? 2 : 1)))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end) {
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 12 ? 2 : 1)))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
   constexpr int PITCH = 4 * QMAX + 4;     // LDS row pitch in floats (pad 16 B: conflict-free b128 writes)
   __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * kWave * PITCH];
@@ -119,10 +130,15 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
   EnvT e;
   const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
   FoodScan<KMAX> fq;          // LDSF: nearest-K selection of the current food set around the current pose
+  int nlive = 0;              // LDSF: live foods of this env, recounted whenever the food set changes
   if constexpr (LDSF) {
     load_core(e, S, P, envc);
-    for (int k = 0; k < P.F; ++k)
-      food.set(k, S.f[(SF_FOOD0 + k) * P.pitch + envc], S.f[(SF_FOOD0 + P.F + k) * P.pitch + envc]);
+    for (int k = 0; k < P.F; ++k) {
+      const double fx = S.f[(SF_FOOD0 + k) * P.pitch + envc];
+      food.set(k, fx, S.f[(SF_FOOD0 + P.F + k) * P.pitch + envc]);
+      nlive += is_none(fx) ? 0 : 1;
+    }
+    for (int k = P.F; k < FMAX; ++k) food.clear(k);   // the scans run over whole groups of four slots
   } else {
     load_env(e, S, P, envc);
   }
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
     o.terminated = o.truncated = o.collision = o.collected = false;
 #else
     StepOut o;
-    if constexpr (LDSF) o = step_env_lds<KMAX, FORCED, STD>(e, food, P, genv, c0, c1, K, fq);
+    if constexpr (LDSF) o = step_env_lds<KMAX, FORCED, STD>(e, food, P, genv, c0, c1, K, fq, nlive);
     else o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
 #endif
     const bool done = o.terminated || o.truncated;
@@ -207,16 +223,18 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
 
     // rare events: respawn of a collected food (snake:179-180), then same-step autoreset
     int todo = (o.collected && P.respawn) ? 1 : 0;
+    const int F_base = P.F_base;
 #ifdef SALP_EXP_NO_RARE   // experiment build: price of the respawn / autoreset region (results are wrong)
     if (false) {
 #else
     if (__any(o.collected || done)) {
 #endif
+      const DevParams& C = cold->P;   // rare path: constants from memory, not from scalar registers
       int limit = 50;
       if (active && io.stats) {
         if (o.collected) atomicAdd(&blk_stats[ST_FOOD], 1ull);
         if (o.collision) atomicAdd(&blk_stats[ST_COLL], 1ull);
-        if (done && P.autoreset) {
+        if (done && C.autoreset) {
           atomicAdd(&blk_stats[ST_EPISODES], 1ull);
           atomicAdd(&blk_stats[o.terminated ? ST_TERM : ST_TRUNC], 1ull);
           atomicAdd(&blk_stats[ST_EPLEN], (unsigned long long)e.eplen);
@@ -225,16 +243,16 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
       }
 #pragma unroll 1
       for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && done && P.autoreset) {
+        if (pass == 1 && done && C.autoreset) {
           if (!FULL && io.final_obs && active) {
             float fo[12 + 4 * KMAX];
             if constexpr (LDSF) {   // the terminal observation sees the respawned food (pass 0)
               bool c_; int h_;
-              scan_foods<KMAX, false>(food, P.F, e.x, e.y, 0.0, fq, c_, h_);
+              scan_foods<KMAX, false, true>(food, C.F, e.x, e.y, 0.0, fq, c_, h_, nlive);
               resolve<KMAX>(food, K, e.x, e.y, fq);
-              observe_lds<KMAX, STD>(e, P, rmax, K, fq, false, 0.f, fo);
+              observe_lds<KMAX, STD>(e, C, rmax, K, fq, nlive, false, 0.f, fo);
             } else {
-              observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, fo);
+              observe<FMAX, KMAX, STD>(e, C, rmax, have_rel, o.rel, fo);
             }
             float4* dst = reinterpret_cast<float4*>(io.final_obs + (rowbase + env) * OD);
 #pragma unroll
@@ -242,34 +260,34 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
               if (q < Q) dst[q] = make_float4(fo[4 * q], fo[4 * q + 1], fo[4 * q + 2], fo[4 * q + 3]);
           }
           if constexpr (LDSF) {
-            todo = reset_core<STD>(e, P, genv);
-            for (int k = 0; k < P.F; ++k) food.clear(k);
+            todo = reset_core<STD>(e, C, genv, F_base);
+            for (int k = 0; k < C.F; ++k) food.clear(k);
           } else {
-            todo = reset_pose<FMAX, STD>(e, P, genv);
+            todo = reset_pose<FMAX, STD>(e, C, genv, F_base);
           }
           limit = 100;
           rmax = CV(R);
           have_rel = false;
         }
 #ifdef SALP_EXP_SERIAL_PLACE
-        if constexpr (LDSF) place_food_lds<STD>(e, food, P, genv, todo, limit);
+        if constexpr (LDSF) place_food_lds<STD>(e, food, C, genv, todo, limit);
 #else
         if constexpr (LDSF) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          place_food_coop<FMAX, STD>(e, food_lds + wave * FMAX * kWave, lane, P, genv, todo, limit);
+          place_food_coop<FMAX, STD>(e, food_lds + wave * FMAX * kWave, lane, C, genv, todo, limit);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 #endif
-        else place_food<FMAX, STD>(e, P, genv, todo, limit);
+        else place_food<FMAX, STD>(e, C, genv, todo, limit);
         todo = 0;
       }
       if constexpr (LDSF) {   // the food set (or the pose) changed: select again for the observation
         bool c_; int h_;
-        scan_foods<KMAX, false>(food, P.F, e.x, e.y, 0.0, fq, c_, h_);
+        scan_foods<KMAX, false, true>(food, C.F, e.x, e.y, 0.0, fq, c_, h_, nlive);
         resolve<KMAX>(food, K, e.x, e.y, fq);
         have_rel = false;
       }
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
 
     if (FULL || io.obs) {
       float ob[12 + 4 * KMAX];
-      if constexpr (LDSF) observe_lds<KMAX, STD>(e, P, rmax, K, fq, have_rel, o.rel, ob);
+      if constexpr (LDSF) observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
       else observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
 #ifdef SALP_EXP_DIRECT_STORE   // experiment: per-lane 96-B rows straight from registers (no LDS transpose)
       if (active) {
@@ -326,16 +344,18 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
   }
 
   if (rows > 0 && active) {
+    const DevParams& C = cold->P;
+    const DevState CS = cold->S;
     if constexpr (LDSF) {
-      store_core(e, S, P, env);
-      for (int k = 0; k < P.F; ++k) {
+      store_core(e, CS, C, env);
+      for (int k = 0; k < C.F; ++k) {
         double fx, fy;
         food.get(k, fx, fy);
-        S.f[(SF_FOOD0 + k) * P.pitch + env] = fx;
-        S.f[(SF_FOOD0 + P.F + k) * P.pitch + env] = fy;
+        CS.f[(SF_FOOD0 + k) * C.pitch + env] = fx;
+        CS.f[(SF_FOOD0 + C.F + k) * C.pitch + env] = fy;
       }
     } else {
-      store_env(e, S, P, env);
+      store_env(e, CS, C, env);
     }
   }
 
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void salp_reset_kernel(DevParams P, DevStat
   const bool resetting = do_reset && (!mask || mask[env]);
   int todo = 0;
   if (resetting) {
-    const int nf = reset_pose<FMAX, STD>(e, P, genv);
+    const int nf = reset_pose<FMAX, STD>(e, P, genv, P.F_base);
     // place_food loops until no lane of the wavefront has food left to place; lanes that are not
     // being reset pass todo = 0
     todo = nf;
@@ -496,6 +516,7 @@ struct salp_vec {
   int std_consts;        // constants equal the reference defaults -> literal-constant kernels
   DevStats* stats;       // device, SALP_STATS_REPLICAS replicas
   int stats_enabled;
+  ColdBlock* cold;       // device copy of P and S for the rollout kernel's rare paths
   // staging for host-pointer calls (grown on demand)
   void* stage;
   size_t stage_bytes;
@@ -561,7 +582,7 @@ int validate(const salp_config_t* c) {
   return SALP_OK;
 }
 
-typedef void (*rollout_fn)(DevParams, DevState, IOPtrs, int, int64_t, int64_t);
+typedef void (*rollout_fn)(DevParams, DevState, IOPtrs, int, int64_t, int64_t, const ColdBlock*);
 typedef void (*reset_fn)(DevParams, DevState, const uint8_t*, float*, int);
 
 template <int FMAX, int KMAX, bool STD, bool RAGGED>
@@ -648,13 +669,13 @@ int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
   if (n_full > 0) {
     const unsigned grid = (unsigned)((n_full + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(rollout_kernel_for<false>(h, full, gen), dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
-                       (int64_t)0, n_full);
+                       (int64_t)0, n_full, (const ColdBlock*)h->cold);
     HIP_TRY(hipGetLastError());
   }
   if (n_full < h->n) {                              // the last n % 64 envs (or the whole small batch): predicated stores
     const unsigned rgrid = (unsigned)((h->n - n_full + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(rollout_kernel_for<true>(h, full, gen), dim3(rgrid), dim3(kBlock), 0, st, h->P, h->S, io, H,
-                       n_full, h->n);
+                       n_full, h->n, (const ColdBlock*)h->cold);
     HIP_TRY(hipGetLastError());
   }
   return SALP_OK;
@@ -725,6 +746,17 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
     salp_vec_destroy(h);
     return fail(e3 == hipErrorOutOfMemory ? SALP_ERR_OOM : SALP_ERR_HIP, m);
   }
+  hipError_t e4 = hipMalloc((void**)&h->cold, sizeof(ColdBlock));
+  if (e4 == hipSuccess) {
+    ColdBlock cb;
+    cb.P = h->P; cb.S = h->S;
+    e4 = hipMemcpy(h->cold, &cb, sizeof(cb), hipMemcpyHostToDevice);
+  }
+  if (e4 != hipSuccess) {
+    std::string m = std::string("hipMalloc/hipMemcpy(cold block): ") + hipGetErrorString(e4);
+    salp_vec_destroy(h);
+    return fail(e4 == hipErrorOutOfMemory ? SALP_ERR_OOM : SALP_ERR_HIP, m);
+  }
   hipError_t e = hipMemset(h->S.f, 0, h->nf_rows * (size_t)pitch * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->S.i, 0, (size_t)SI_COUNT * (size_t)pitch * sizeof(int32_t));
   if (e == hipSuccess) e = hipMemset(h->stats, 0, SALP_STATS_REPLICAS * sizeof(DevStats));
@@ -750,6 +782,7 @@ void salp_vec_destroy(salp_vec_t* h) {
   if (h->S.f) (void)hipFree(h->S.f);
   if (h->S.i) (void)hipFree(h->S.i);
   if (h->stats) (void)hipFree(h->stats);
+  if (h->cold) (void)hipFree(h->cold);
   if (h->stage) (void)hipFree(h->stage);
   if (h->act_buf) (void)hipFree(h->act_buf);
   delete h;
