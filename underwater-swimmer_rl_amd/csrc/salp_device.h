@@ -96,6 +96,7 @@ enum { ST_STEPS = 0, ST_EPISODES, ST_TERM, ST_TRUNC, ST_COLL, ST_FOOD, ST_EPLEN,
 
 // ------------------------------------------------------------------ Philox4x32-10
 struct U4 { uint32_t x, y, z, w; };
+// (gfx950 has no v_xor3_b32: the two xors per word stay two instructions.)
 __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                             uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -254,6 +255,95 @@ __device__ __forceinline__ double sin_nozzle(double x) {
   return fma(x * z, p, x);
 }
 
+// ---- thrust-block constants through the scalar cache ------------------------------------------------
+// gfx950 has no 64-bit literals: every fp64 constant of a kernel is an s_mov_b32 pair (or a v_mov_b32 pair
+// when it is the addend of a v_fmac_f64), and the wavefront issues ONE instruction of any kind per 4 cycles
+// (SQ counters, profiles/r02/ab_notes.md): in the 12-food kernel ~250 of ~1200 instructions per step were
+// such moves, 99 of them in the thrust block.  The constants of the thrust block therefore sit in a table in
+// constant memory and are fetched with scalar loads — one s_load_dwordx8/x16 brings 4 / 8 of them into SGPRs,
+// which v_fma_f64 / v_mul_f64 take directly as an operand.  The table pointer is made opaque at the point of
+// use so that the loads stay inside the (conditional) thrust block instead of being hoisted across the step
+// loop, where they would only be spilled.  Values and evaluation order are those of sincos_small / sin_nozzle
+// above: results are bit-identical.
+typedef const double __attribute__((address_space(4))) tbl_double;
+enum {
+  TT_2OPI = 0, TT_PIO2_1, TT_PIO2_1T, TT_S5, TT_S4, TT_S3, TT_S2, TT_S1,          // sincos reduction, sin kernel
+  TT_S0, TT_C6, TT_C5, TT_C4, TT_C3, TT_C2, TT_C1, TT_PAD0,                        // cos kernel
+  TT_N10, TT_N9, TT_N8, TT_N7, TT_N6, TT_N5, TT_N4, TT_N3,                         // sin_nozzle
+  TT_N2, TT_N1, TT_K012, TT_K0002, TT_K07, TT_K00005, TT_K00003, TT_PIO2,          // thrust scalings
+  TT_DL, TT_K03, TT_K008, TT_K005, TT_J_S3, TT_J_S2, TT_J_S1, TT_J_S0,             // side thrust, jitter sin
+  TT_J_C3, TT_J_C2, TT_J_C1, TT_K004, TT_K0002J, TT_K04, TT_COUNT
+};
+__constant__ double kThrustTbl[TT_COUNT + 2] = {
+  6.36619772367581382433e-01, 1.57079632673412561417e+00, 6.07710050650619224932e-11,
+  1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06, -1.98412698298579493134e-04,
+  8.33333333332248946124e-03,
+  -1.66666666666666324348e-01, -1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07,
+  2.48015872894767294178e-05, -1.38888888888741095749e-03, 4.16666666666666019037e-02, 0.0,
+  1.9572941063391263e-20, -8.2206352466243295e-18, 2.8114572543455206e-15, -7.6471637318198164e-13,
+  1.6059043836821613e-10, -2.5052108385441720e-08, 2.7557319223985893e-06, -1.9841269841269841e-04,
+  8.3333333333333332e-03, -1.6666666666666666e-01, 0.012, 0.0002, 0.7, 0.00005, 0.00003, 1.5707963267948966,
+  -6.123233995736766e-17, 0.3, 0.008, 0.05, 2.7557319223985893e-06, -1.9841269841269841e-04, 8.3333333333333332e-03,
+  -1.6666666666666666e-01,
+  2.4801587301587302e-05, -1.3888888888888889e-03, 4.1666666666666664e-02, 0.04, 0.002, 0.4, 0.0, 0.0
+};
+__device__ __forceinline__ tbl_double* thrust_table() {
+  tbl_double* t = (tbl_double*)kThrustTbl;
+  asm volatile("" : "+s"(t));
+  return t;
+}
+// a * b + c and a * c with the constant c in an SGPR pair, written as instructions: left to itself the
+// compiler copies a scalar addend into VGPRs (two v_mov_b32) to use the two-address v_fmac_f64.
+__device__ __forceinline__ double fma_s(double a, double b, double c_uniform) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+  return r;
+}
+__device__ __forceinline__ double mul_s(double a, double c_uniform) {
+  double r;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c_uniform));
+  return r;
+}
+__device__ __forceinline__ void sincos_small_t(tbl_double* T, double x, double& s, double& c) {
+  const double fn = __builtin_rint(mul_s(x, T[TT_2OPI]));
+  const double nfn = -fn;
+  double r = fma(nfn, T[TT_PIO2_1], x);
+  r = fma(nfn, T[TT_PIO2_1T], r);
+  const double z = r * r;
+  double ps = fma_s(z, (double)T[TT_S5], T[TT_S4]);
+  ps = fma_s(z, ps, T[TT_S3]);
+  ps = fma_s(z, ps, T[TT_S2]);
+  ps = fma_s(z, ps, T[TT_S1]);
+  const double v = z * r;
+  const double sr = fma(v, fma_s(z, ps, T[TT_S0]), r);
+  double pc = fma_s(z, (double)T[TT_C6], T[TT_C5]);
+  pc = fma_s(z, pc, T[TT_C4]);
+  pc = fma_s(z, pc, T[TT_C3]);
+  pc = fma_s(z, pc, T[TT_C2]);
+  pc = fma_s(z, pc, T[TT_C1]);
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double cr = w + (((1.0 - w) - hz) + z * (z * pc));
+  const int q = (int)fn & 3;
+  const double s0 = (q & 1) ? cr : sr;
+  const double c0 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s0 : s0;
+  c = ((q + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ double sin_nozzle_t(tbl_double* T, double x) {
+  const double z = x * x;
+  double p = fma_s(z, (double)T[TT_N10], T[TT_N9]);
+  p = fma_s(z, p, T[TT_N8]);
+  p = fma_s(z, p, T[TT_N7]);
+  p = fma_s(z, p, T[TT_N6]);
+  p = fma_s(z, p, T[TT_N5]);
+  p = fma_s(z, p, T[TT_N4]);
+  p = fma_s(z, p, T[TT_N3]);
+  p = fma_s(z, p, T[TT_N2]);
+  p = fma_s(z, p, T[TT_N1]);
+  return fma(x * z, p, x);
+}
+
 // Ellipse semi-axes implied by the post-step state (see SALP_I_SHAPE_HOLD in salp_vec.h).
 template <bool STD>
 __device__ __forceinline__ void shape_of(const DevParams& P, uint32_t packed, double water, double& a, double& b) {
@@ -342,52 +432,54 @@ __device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint
 // rounding error of the addition, the jitter angle a rotation by |D| <= 0.025 (short series).
 template <int FMAX, bool STD>
 __device__ __forceinline__ void apply_jet_thrust(EnvCore& e, const DevParams& P, uint64_t genv, double r) {
-  const double T = (CV(thrust_force) * e.water) * 0.4;
+  tbl_double* TT = thrust_table();
+  const double T = mul_s(CV(thrust_force) * e.water, TT[TT_K04]);
   const double phi = e.th - e.noz;
   double s, c;
-  sincos_small(phi, s, c);
-  e.vx = e.vx + (c * T) * 0.012;
-  e.vy = e.vy + (s * T) * 0.012;
+  sincos_small_t(TT, phi, s, c);
+  e.vx = e.vx + mul_s(c * T, TT[TT_K012]);
+  e.vy = e.vy + mul_s(s * T, TT[TT_K012]);
   const double nn = -e.noz;
-  const double primary = (nn * T) * 0.0002;
-  const double arm = r * 0.7;
-  const double perp = T * sin_nozzle(nn);
-  const double moment = (perp * arm) * 0.00005;
-  const double shape = ((nn * T) * e.water) * 0.00003;
+  const double primary = mul_s(nn * T, TT[TT_K0002]);
+  const double arm = r * TT[TT_K07];
+  const double perp = T * sin_nozzle_t(TT, nn);
+  const double moment = mul_s(perp * arm, TT[TT_K00005]);
+  const double shape = mul_s((nn * T) * e.water, TT[TT_K00003]);
   e.om = e.om + ((primary + moment) + shape);
   {  // side thrust at fl(phi + fl(pi/2)) = phi + pi/2 + dl,  dl = (fl(pi/2) - pi/2) - err
-    const double side = phi + SALP_PIO2;
+    const double pio2 = TT[TT_PIO2];
+    const double side = phi + pio2;
     const double bb = side - phi;
-    const double err = (phi - (side - bb)) + (SALP_PIO2 - bb);   // phi + PIO2 = side + err exactly
-    const double dl = -6.123233995736766e-17 - err;
+    const double err = (phi - (side - bb)) + (pio2 - bb);   // phi + PIO2 = side + err exactly
+    const double dl = TT[TT_DL] - err;
     const double sc = -fma(dl, c, s);     // cos(side) = -sin(phi + dl)
     const double ss = fma(-dl, s, c);     // sin(side) =  cos(phi + dl)
-    const double S = (T * fabs(e.noz)) * 0.3;
-    e.vx = e.vx + (sc * S) * 0.008;
-    e.vy = e.vy + (ss * S) * 0.008;
+    const double S = mul_s(T * fabs(e.noz), TT[TT_K03]);
+    e.vx = e.vx + mul_s(sc * S, TT[TT_K008]);
+    e.vy = e.vy + mul_s(ss * S, TT[TT_K008]);
   }
   {  // jitter at fl(phi + d), d = fl((u - 0.5) * 0.05)
     const U4 w = next_block(e, P, genv);
     const double u = u53(w.x, w.y);
-    const double d = (u - 0.5) * 0.05;
+    const double d = mul_s(u - 0.5, TT[TT_K005]);
     const double na = phi + d;
     const double bb = na - phi;
     const double err = (phi - (na - bb)) + (d - bb);
     const double D = d - err;             // na = phi + D (to ~1e-18)
     const double z = D * D;
-    double sp = fma(z, 2.7557319223985893e-06, -1.9841269841269841e-04);
-    sp = fma(z, sp, 8.3333333333333332e-03);
-    sp = fma(z, sp, -1.6666666666666666e-01);
+    double sp = fma_s(z, (double)TT[TT_J_S3], TT[TT_J_S2]);
+    sp = fma_s(z, sp, TT[TT_J_S1]);
+    sp = fma_s(z, sp, TT[TT_J_S0]);
     const double sD = fma(D * z, sp, D);
-    double cp = fma(z, 2.4801587301587302e-05, -1.3888888888888889e-03);
-    cp = fma(z, cp, 4.1666666666666664e-02);
+    double cp = fma_s(z, (double)TT[TT_J_C3], TT[TT_J_C2]);
+    cp = fma_s(z, cp, TT[TT_J_C1]);
     cp = fma(z, cp, -0.5);
     const double cD = fma(z, cp, 1.0);
     const double nc = c * cD - s * sD;
     const double ns = s * cD + c * sD;
-    const double nf = T * 0.04;
-    e.vx = e.vx + (nc * nf) * 0.002;
-    e.vy = e.vy + (ns * nf) * 0.002;
+    const double nf = T * TT[TT_K004];
+    e.vx = e.vx + mul_s(nc * nf, TT[TT_K0002J]);
+    e.vy = e.vy + mul_s(ns * nf, TT[TT_K0002J]);
   }
 }
 
@@ -457,6 +549,46 @@ __device__ __forceinline__ float relative_heading(float dy, float dx, float th) 
   return rel;
 }
 
+// fp64 constants of the per-step path, held in VGPRs across the step loop (multi-food kernels).
+// gfx950 has no 64-bit literals: an fp64 constant operand is two s_mov_b32 (or two v_mov_b32 when it is
+// the addend of a v_fmac_f64) in front of its use, and a wavefront issues one instruction of any kind per
+// 4 cycles — in the 12-food kernel ~150 of ~1200 instructions per step were such moves outside the thrust
+// block.  The multi-food kernels are issue-bound at 2 wavefronts per SIMD and have the registers (<= 256):
+// their constants are made opaque once before the loop (vreg_const), which pins them in VGPR pairs that
+// VALU instructions read directly.  The one-food kernel (write-bound, 4 wavefronts per SIMD at <= 128 VGPRs)
+// keeps the literals: KV() resolves to CV() there at compile time.
+struct HotK {
+  double max_nozzle, nozzle_rate, inhale_d, a_rest, b_rest, da_inh, db_inh, ab_full, da_exh, db_exh;
+  double water_min, exhale_d, p3, p1, drag, ang_drag, pi, twopi, margin, W, H, k04, k07;
+  double wall_hi_x, wall_hi_y, food_radius, cap_slack;
+};
+__device__ __forceinline__ double vreg_const(double c) {
+  asm volatile("" : "+v"(c));
+  return c;
+}
+template <bool STD, bool HOIST>
+__device__ __forceinline__ HotK make_hotk(const DevParams& P) {
+  HotK k;
+  if constexpr (HOIST) {
+    k.max_nozzle = vreg_const(CV(max_nozzle)); k.nozzle_rate = vreg_const(CV(nozzle_rate));
+    k.inhale_d = vreg_const((double)CV(inhale_dur));
+    k.a_rest = vreg_const(CV(a_rest)); k.b_rest = vreg_const(CV(b_rest));
+    k.da_inh = vreg_const(CV(da_inh)); k.db_inh = vreg_const(CV(db_inh));
+    k.ab_full = vreg_const(CV(ab_full)); k.da_exh = vreg_const(CV(da_exh)); k.db_exh = vreg_const(CV(db_exh));
+    k.water_min = vreg_const(0.05); k.exhale_d = vreg_const(CV(exhale_dur_d)); k.p3 = vreg_const(0.3);
+    k.p1 = vreg_const(0.1);
+    k.drag = vreg_const(CV(drag)); k.ang_drag = vreg_const(CV(ang_drag));
+    k.pi = vreg_const(SALP_PI); k.twopi = vreg_const(SALP_2PI);
+    k.margin = vreg_const(CV(margin)); k.W = vreg_const(CV(W)); k.H = vreg_const(CV(H));
+    k.k04 = vreg_const(0.4); k.k07 = vreg_const(0.7);
+    k.wall_hi_x = vreg_const(CV(wall_hi_x)); k.wall_hi_y = vreg_const(CV(wall_hi_y));
+    k.food_radius = vreg_const(CV(food_radius)); k.cap_slack = vreg_const(1.00000000001);
+  }
+  return k;
+}
+// KV(field, literal-or-CV expression): the hoisted copy when HOIST, else the expression itself
+#define KV(field, expr) (HOIST ? hk.field : (expr))
+
 struct StepOut {
   double rmax;    // max(ellipse_a, ellipse_b) of this step
   float reward;
@@ -470,8 +602,8 @@ struct StepOut {
 // limit = 50) when o.collected && P.respawn, BEFORE any autoreset so the draw order of the
 // reference is kept.  (The all-collected termination test only applies when !P.respawn.)
 // legacy:119-156 up to and including the wall bounce; returns r = max(ellipse_a, ellipse_b) of this step.
-template <bool FORCED, bool STD>
-__device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint64_t genv, float a0, float a1) {
+template <bool FORCED, bool STD, bool HOIST = false>
+__device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint64_t genv, float a0, float a1, const HotK& hk = HotK()) {
   int phase = bw_phase(e.packed), timer = bw_timer(e.packed), dur = bw_dur(e.packed);
   // legacy:121-135
   double nd;
@@ -484,14 +616,15 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
     inhaling = a0 > 0.5f;
     nd = (double)a1;
   }
-  const double target = nd * CV(max_nozzle);
+  const double max_noz = KV(max_nozzle, CV(max_nozzle)), noz_rate = KV(nozzle_rate, CV(nozzle_rate));
+  const double target = nd * max_noz;
   // legacy:169-182 _update_nozzle
   {
     const double diff = target - e.noz;
     double nz;
-    if (fabs(diff) > CV(nozzle_rate)) nz = (diff > 0) ? (e.noz + CV(nozzle_rate)) : (e.noz - CV(nozzle_rate));
+    if (fabs(diff) > noz_rate) nz = (diff > 0) ? (e.noz + noz_rate) : (e.noz - noz_rate);
     else nz = target;
-    e.noz = pymax(-CV(max_nozzle), pymin(CV(max_nozzle), nz));
+    e.noz = pymax(-max_noz, pymin(max_noz, nz));
   }
   // legacy:184-259 _update_breathing_cycle
   double a, b;
@@ -500,21 +633,42 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
   double water_next = e.water;
   {
     const int tnew = timer + 1;
-    const double den = (phase == 2) ? (double)dur : (double)CV(inhale_dur);
+    const double den = (phase == 2) ? (double)dur : KV(inhale_d, (double)CV(inhale_dur));
+    // p = tnew / den, correctly rounded, without the fp64 division sequence (~14 VALU incl. v_rcp_f64): with
+    // y = RN(1 / den), q0 = RN(tnew y), r = tnew - den q0 (exact in an fma), RN(q0 + r y) is the IEEE quotient
+    // (Markstein) — checked exhaustively for every den in 1..255 and tnew in 1..257.  y is a constant for the
+    // inhale duration and for a full exhale (dur = exhale_duration, every exhale of forced breathing); lanes
+    // whose exhale was cut short (dur from the water level, legacy:223) divide once to get theirs.
+    double yden = (phase == 2) ? (1.0 / (double)CV(exhale_dur)) : (1.0 / (double)CV(inhale_dur));
+    {
+      const bool odd = (phase == 2) && (dur != CV(exhale_dur));
+      if (__any(odd)) {
+        asm volatile("" ::: "memory");   // keeps the division inside the (wave-uniform) branch: not speculated
+        if (odd) yden = 1.0 / (double)dur;
+      }
+    }
+    const double a_rest = KV(a_rest, CV(a_rest)), b_rest = KV(b_rest, CV(b_rest)), da_inh = KV(da_inh, CV(da_inh)), db_inh = KV(db_inh, CV(db_inh));
+    const double ab_full = KV(ab_full, CV(ab_full)), da_exh = KV(da_exh, CV(da_exh)), db_exh = KV(db_exh, CV(db_exh));
+#ifdef SALP_EXP_IEEE_DIV
     const double p = (double)tnew / den;
+#else
+    const double tn = (double)tnew;
+    const double q0 = tn * yden;
+    const double p = fma(fma(-den, q0, tn), yden, q0);
+#endif
     if (phase == 0) {
-      a = CV(a_rest); b = CV(b_rest);
+      a = a_rest; b = b_rest;
       if (inhaling) { phase = 1; timer = 0; }
     } else if (phase == 1) {
       if (inhaling && timer < CV(inhale_dur)) {
         timer = tnew;
-        a = CV(a_rest) + CV(da_inh) * p; b = CV(b_rest) + CV(db_inh) * p;
+        a = a_rest + da_inh * p; b = b_rest + db_inh * p;
         water_next = p;
       } else {
-        a = CV(a_rest) + CV(da_inh) * e.water; b = CV(b_rest) + CV(db_inh) * e.water;  // unchanged ellipse
-        if (e.water > 0.05) {
+        a = a_rest + da_inh * e.water; b = b_rest + db_inh * e.water;  // unchanged ellipse
+        if (e.water > KV(water_min, 0.05)) {
           phase = 2; timer = 0;
-          dur = (int)(CV(exhale_dur_d) * pymax(e.water, 0.3));
+          dur = (int)(KV(exhale_d, CV(exhale_dur_d)) * pymax(e.water, KV(p3, 0.3)));
         } else {
           hold = (timer >= 1 && timer <= 6) ? timer : 0;
           phase = 0; timer = 0; water_next = 0.0;
@@ -523,12 +677,12 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
     } else {
       if (p <= 1.0) {
         timer = tnew;
-        a = CV(ab_full) + CV(da_exh) * p; b = CV(ab_full) + CV(db_exh) * p;
-        thrust = (0.1 <= p) && (p <= 0.5);
+        a = ab_full + da_exh * p; b = ab_full + db_exh * p;
+        thrust = (KV(p1, 0.1) <= p) && (p <= 0.5);
         const double v = e.water * (1.0 - p);
         water_next = (v > 0) ? v : 0.0;
       } else {
-        a = CV(ab_full) + CV(da_exh) * 1.0; b = CV(ab_full) + CV(db_exh) * 1.0;  // ellipse of the last exhale step
+        a = ab_full + da_exh * 1.0; b = ab_full + db_exh * 1.0;  // ellipse of the last exhale step
         phase = 0; timer = 0; water_next = 0.0;
       }
     }
@@ -541,26 +695,28 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
   e.water = water_next;
   e.packed = pack_breath(phase, timer, dur, hold);
   // legacy:316-352 _update_physics
-  e.vx = e.vx * CV(drag); e.vy = e.vy * CV(drag); e.om = e.om * CV(ang_drag);
+  e.vx = e.vx * KV(drag, CV(drag)); e.vy = e.vy * KV(drag, CV(drag)); e.om = e.om * KV(ang_drag, CV(ang_drag));
   e.x = e.x + e.vx; e.y = e.y + e.vy; e.th = e.th + e.om;
   // legacy:329-332 `while theta > pi: theta -= 2 pi` / `while theta < -pi: ...`.  |omega| is far below
   // 2 pi, so one conditional step each is the common case; the (bounded) loops only run if a lane
   // is still outside, e.g. after an injected state.
-  if (e.th > SALP_PI) e.th -= SALP_2PI;
-  if (e.th < -SALP_PI) e.th += SALP_2PI;
-  if (__any(e.th > SALP_PI || e.th < -SALP_PI)) {
+  const double pi = KV(pi, SALP_PI), twopi = KV(twopi, SALP_2PI);
+  if (e.th > pi) e.th -= twopi;
+  if (e.th < -pi) e.th += twopi;
+  if (__any(e.th > pi || e.th < -pi)) {
 #pragma unroll 1
-    for (int it = 0; it < 8 && e.th > SALP_PI; ++it) e.th -= SALP_2PI;
+    for (int it = 0; it < 8 && e.th > pi; ++it) e.th -= twopi;
 #pragma unroll 1
-    for (int it = 0; it < 8 && e.th < -SALP_PI; ++it) e.th += SALP_2PI;
+    for (int it = 0; it < 8 && e.th < -pi; ++it) e.th += twopi;
   }
   {
-    const double m = CV(margin) + r;
-    const double hx = CV(W) - m, hy = CV(H) - m;
-    if (e.x < m) { e.x = m; e.vx = fabs(e.vx) * 0.4; e.om = e.om * 0.7; }
-    else if (e.x > hx) { e.x = hx; e.vx = -fabs(e.vx) * 0.4; e.om = e.om * 0.7; }
-    if (e.y < m) { e.y = m; e.vy = fabs(e.vy) * 0.4; e.om = e.om * 0.7; }
-    else if (e.y > hy) { e.y = hy; e.vy = -fabs(e.vy) * 0.4; e.om = e.om * 0.7; }
+    const double m = KV(margin, CV(margin)) + r;
+    const double hx = KV(W, CV(W)) - m, hy = KV(H, CV(H)) - m;
+    const double k04 = KV(k04, 0.4), k07 = KV(k07, 0.7);
+    if (e.x < m) { e.x = m; e.vx = fabs(e.vx) * k04; e.om = e.om * k07; }
+    else if (e.x > hx) { e.x = hx; e.vx = -fabs(e.vx) * k04; e.om = e.om * k07; }
+    if (e.y < m) { e.y = m; e.vy = fabs(e.vy) * k04; e.om = e.om * k07; }
+    else if (e.y > hy) { e.y = hy; e.vy = -fabs(e.vy) * k04; e.om = e.om * k07; }
   }
   return r;
 }

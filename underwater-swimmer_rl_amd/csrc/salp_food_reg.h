@@ -1,0 +1,208 @@
+// salp_food_reg.h — the multi-food side of the rollout kernel for up to 12 food slots (the presets: 5 in
+// defaults.yaml, 12 in sac_gail.yaml), with the food positions of an env in VGPRs.
+//
+// The LDS-resident form (salp_food_lds.h, still used above 12 slots and by the generic instantiation) costs
+// 16 B x slots x 64 lanes of LDS per wavefront: with 12 slots 12 KB, which caps the CU at 8 wavefronts
+// (2 per SIMD), and the kernel is issue-bound with the VALU ~58 % busy at that residency.  Since the step loop
+// no longer keeps ~45 VGPRs of hoisted constants (build.py: no machine LICM) the 48 VGPRs of 12 positions fit
+// under the 168-VGPR budget of 3 wavefronts per SIMD.  What registers cannot do is per-lane dynamic indexing —
+// the K selected foods are only known as slot numbers after the pass — so the pass leaves each slot's fp32
+// offset (dx, dy) in a small per-wavefront LDS block (8 B per slot and lane, half the LDS of the positions,
+// written once per slot and step, read K times), and the selection reads its K offsets from there.  The
+// arithmetic on each food is the reference's, in its order, exactly as in salp_food_lds.h.
+#pragma once
+#include "salp_food_lds.h"
+
+namespace salp {
+
+struct OffsetLds {
+  float2* col;   // this lane's column of the wavefront's [FMAX][64] block of (dx, dy) in fp32
+};
+
+// One pass over the slots (see scan_foods in salp_food_lds.h for CAPTURE / COUNT).  Groups of four slots
+// beyond F are skipped (wave-uniform); slots F..FMAX-1 inside a processed group are empty (NaN).
+template <int FMAX, int KMAX, bool CAPTURE, bool COUNT>
+__device__ __forceinline__ void scan_foods_reg(const Env<FMAX>& e, const OffsetLds& sc, int F, double cr2, FoodScan<KMAX>& q,
+                                               bool& collected, int& hit_k, int& cnt) {
+  const double dead = dead_key();
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) q.key[s] = dead;
+  float dsum = 0.f;
+  int n = 0;
+  collected = false;
+  hit_k = 0;
+#pragma unroll
+  for (int k0 = 0; k0 < FMAX; k0 += 4) {
+    if (k0 < F) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j;
+        if (k < FMAX) {
+          const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
+          double d2 = dx * dx + dy * dy;                 // NaN for an empty slot
+          if (CAPTURE) {
+            const bool hit = !collected && (d2 < cr2);   // NaN never hits
+            collected = collected || hit;
+            hit_k = hit ? k : hit_k;
+            d2 = hit ? __builtin_nan("") : d2;
+          }
+          if (COUNT) n += (d2 == d2) ? 1 : 0;
+          dsum += __builtin_fmaxf(__builtin_amdgcn_sqrtf((float)d2), 0.f);   // maxnum: NaN (empty) adds 0
+          sc.col[k * kFoodLanes] = make_float2((float)dx, (float)dy);
+          double cv = pack_key(min_key_s(d2, dead), k);
+#pragma unroll
+          for (int s = 0; s < KMAX; ++s) {
+            const double lo = min_key(cv, q.key[s]);
+            if (s + 1 < KMAX) cv = max_key(cv, q.key[s]);
+            q.key[s] = lo;
+          }
+        }
+      }
+    }
+  }
+  q.dsum = dsum;
+  if (COUNT) cnt = n;
+}
+
+// fp32 geometry of the first K selected foods: the offsets the pass left in LDS, the distance from the key
+// (the squared distance to within 16 ulp of fp64: the same float except on ~3e-8 of the values, then 1 ulp).
+template <int KMAX>
+__device__ __forceinline__ void resolve_reg(const OffsetLds& sc, int K, FoodScan<KMAX>& q) {
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    q.bx[s] = 0.f; q.by[s] = 0.f; q.bd[s] = 0.f; q.idx[s] = -1;
+    if (s < K) {
+      const int k = key_slot(q.key[s]);
+      const bool found = key_found(q.key[s]);
+      const float2 o = sc.col[k * kFoodLanes];
+      q.idx[s] = found ? k : -1;
+      q.bx[s] = found ? o.x : 0.f;
+      q.by[s] = found ? o.y : 0.f;
+      q.bd[s] = found ? __builtin_amdgcn_sqrtf((float)q.key[s]) : 0.f;
+    }
+  }
+}
+
+// slot `k` (per-lane) := empty, for the lanes with `doit`
+template <int FMAX>
+__device__ __forceinline__ void clear_slot(Env<FMAX>& e, bool doit, int k) {
+#pragma unroll
+  for (int j = 0; j < FMAX; ++j) {
+    const bool m = doit && (k == j);
+    e.fx[j] = m ? __builtin_nan("") : e.fx[j];
+    e.fy[j] = m ? __builtin_nan("") : e.fy[j];
+  }
+}
+
+// One reference step of a multi-food env (the register counterpart of step_env_lds).
+template <int FMAX, int KMAX, bool FORCED, bool STD, bool HOIST>
+__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& sc, const DevParams& P, const HotK& hk, uint64_t genv,
+                                                float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive) {
+  const double r = step_head<FORCED, STD, HOIST>(e, P, genv, a0, a1, hk);
+  StepOut o;
+  o.rmax = r;
+  const double cr = r + KV(food_radius, CV(food_radius));
+  const double cr2 = cr * cr;
+  int hit_k, cnt_;
+  scan_foods_reg<FMAX, KMAX, false, false>(e, sc, P.F, 0.0, q, o.collected, hit_k, cnt_);
+  if (__any(q.key[0] < cr2 * KV(cap_slack, 1.00000000001))) {   // see step_env_lds
+    scan_foods_reg<FMAX, KMAX, true, true>(e, sc, P.F, cr2, q, o.collected, hit_k, nlive);
+    clear_slot<FMAX>(e, o.collected, hit_k);
+  }
+  resolve_reg<KMAX>(sc, K > 0 ? K : 1, q);   // the reward needs the nearest even when K = 0
+  {
+    const double mg = KV(margin, CV(margin));
+    o.collision = (e.x - r <= mg) || (e.x + r >= KV(wall_hi_x, CV(wall_hi_x))) || (e.y - r <= mg) || (e.y + r >= KV(wall_hi_y, CV(wall_hi_y)));
+  }
+  double rew = 0.0;
+  if (o.collected) {
+    rew += P.food_reward;
+    if (P.efficiency_bonus > 0) rew += P.efficiency_bonus * (double)(P.max_steps_wo_food - e.ssf);
+  }
+  if (o.collision) rew += P.collision_penalty;
+  o.rel = relative_heading(q.by[0], q.bx[0], (float)e.th);
+  o.rel_valid = q.idx[0] >= 0;
+  if (P.prox_w > 0) {
+    const double al = P.prox_w * (double)cos_wrapped(o.rel);
+    rew += o.rel_valid ? al : 0.0;
+  }
+  rew += P.time_penalty;
+  step_tail(e, P, o, rew, nlive > 0);
+  return o;
+}
+
+// Wavefront-cooperative placement (place_food_coop of salp_food_lds.h) on register-resident foods: the foods
+// of the env being served (lane L) are broadcast with v_readlane (slot index static, L wave-uniform), an
+// accepted point is written into lane L's slot through a wave-uniform switch.  Draws, order and stream
+// consumption are exactly those of the serial sampler (place_food in salp_device.h).
+template <int FMAX, bool STD>
+__device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, int lane, const DevParams& P, uint64_t genv, int todo, int limit) {
+  unsigned long long need = __ballot(todo > 0);
+  const double min2 = CV(min_food_dist2);
+  // empty slots of the own env as a bit mask (bit k: slot k < F is empty)
+  uint32_t my_empty = 0u;
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) my_empty |= (k < P.F && is_none(e.fx[k])) ? (1u << k) : 0u;
+  while (need) {                                   // wave-uniform: one env at a time
+    const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)need) - 1);
+    need &= need - 1;
+    const uint32_t g_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)genv, L);
+    const uint32_t g_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(genv >> 32), L);
+    const uint32_t rng0 = (uint32_t)__builtin_amdgcn_readlane((int)e.rng, L);
+    const double rx = bcast_lane(e.x, L), ry = bcast_lane(e.y, L);
+    int todo_l = __builtin_amdgcn_readlane(todo, L);
+    const int limit_l = __builtin_amdgcn_readlane(limit, L);
+    uint32_t empty = (uint32_t)__builtin_amdgcn_readlane((int)my_empty, L);
+    uint32_t consumed = 0;                         // draws of env L's stream used so far
+    int attempts = 0;
+    while (todo_l > 0) {
+      // 64 candidates: draw number consumed + lane
+      const U4 w = philox4x32_10(g_lo, g_hi, rng0 + consumed + (uint32_t)lane, 0u, P.seed_lo, P.seed_hi);
+      const double x = CV(food_xlo) + CV(food_xspan) * u53(w.x, w.y);
+      const double y = CV(food_ylo) + CV(food_yspan) * u53(w.z, w.w);
+      bool ok;
+      {
+        const double dx = x - rx, dy = y - ry;
+        ok = !(dx * dx + dy * dy < min2);
+      }
+#pragma unroll
+      for (int k = 0; k < FMAX; ++k) {
+        if (k < P.F) {                             // wave-uniform
+          const double fxk = bcast_lane(e.fx[k], L), fyk = bcast_lane(e.fy[k], L);
+          const double dx = x - fxk, dy = y - fyk;
+          ok = ok && !(dx * dx + dy * dy < min2);  // NaN (empty) slots never reject
+        }
+      }
+      int j = 0;                                   // first candidate of this batch not yet judged
+      while (todo_l > 0 && j < kFoodLanes) {
+        const unsigned long long okm = __ballot(ok) & (~0ull << j);
+        const int first_ok = okm ? (__ffsll((long long)okm) - 1) : kFoodLanes;
+        const int forced = j + (limit_l - attempts);          // accepted whatever it is
+        const int a = __builtin_amdgcn_readfirstlane(first_ok < forced ? first_ok : forced);
+        if (a >= kFoodLanes) { attempts += kFoodLanes - j; j = kFoodLanes; break; }
+        const double ax = bcast_lane(x, a), ay = bcast_lane(y, a);
+        if (empty) {                               // first empty slot (snake:120, 261-264)
+          const int slot = __builtin_amdgcn_readfirstlane(__ffs((int)empty) - 1);
+          empty &= empty - 1;
+#pragma unroll
+          for (int k = 0; k < FMAX; ++k) {
+            if (slot == k) {                       // wave-uniform
+              if (lane == L) { e.fx[k] = ax; e.fy[k] = ay; }
+            }
+          }
+        }
+        {
+          const double dx = x - ax, dy = y - ay;
+          ok = ok && !(dx * dx + dy * dy < min2);
+        }
+        todo_l -= 1;
+        attempts = 0;
+        j = a + 1;
+      }
+      consumed += (uint32_t)j;
+    }
+    if (lane == L) e.rng = rng0 + consumed;
+  }
+}
+
+}  // namespace salp

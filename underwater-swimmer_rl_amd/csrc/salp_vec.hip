@@ -24,6 +24,7 @@
 #include "../../include/salp_vec.h"
 #include "salp_device.h"
 #include "salp_food_lds.h"
+#include "salp_food_reg.h"
 
 using namespace salp;
 
@@ -35,6 +36,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #endif
 constexpr int kBlock = SALP_BLOCK;
 constexpr int kWave = 64;
+#ifdef SALP_EXP_HOIST
+#define SALP_MULTI_WAVES 2
+#else
+#define SALP_MULTI_WAVES 3     // multi-food kernels (<= 12 slots): <= 168 VGPRs, 3 wavefronts per SIMD
+#endif
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -82,17 +88,22 @@ struct ColdBlock {
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
 template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 12 ? 2 : 1)))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_WAVES : 1))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
   constexpr int PITCH = 4 * QMAX + 4;     // LDS row pitch in floats (pad 16 B: conflict-free b128 writes)
   __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * kWave * PITCH];
-#ifdef SALP_EXP_REG_FOOD      // experiment build: multi-food envs with the foods in registers (the round-1 form)
-  constexpr bool LDSF = false;
-#else
-  // multi-food envs keep their food positions in LDS (salp_food_lds.h); one food stays in registers
+  // Where the food positions of a multi-food env live: up to 12 slots in VGPRs (salp_food_reg.h: the pass
+  // leaves fp32 offsets in a small LDS block), above that in LDS (salp_food_lds.h); one food is plain registers.
+#ifdef SALP_EXP_LDS_FOOD      // experiment build: the LDS-resident form for every multi-food kernel
+  constexpr bool REGF = false;
   constexpr bool LDSF = FMAX > 1;
+#else
+  constexpr bool REGF = FMAX > 1 && FMAX <= 12;
+  constexpr bool LDSF = FMAX > 12;
 #endif
+  constexpr bool MULTI = REGF || LDSF;
   __shared__ __attribute__((aligned(16))) double2 food_lds[LDSF ? (kBlock / kWave) * FMAX * kWave : 1];
+  __shared__ __attribute__((aligned(16))) float2 off_lds[REGF ? (kBlock / kWave) * FMAX * kWave : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -129,8 +140,9 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
   using EnvT = std::conditional_t<LDSF, EnvCore, Env<FMAX>>;
   EnvT e;
   const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
-  FoodScan<KMAX> fq;          // LDSF: nearest-K selection of the current food set around the current pose
-  int nlive = 0;              // LDSF: live foods of this env, recounted whenever the food set changes
+  const OffsetLds offs{off_lds + (REGF ? (wave * FMAX * kWave + lane) : 0)};
+  FoodScan<KMAX> fq;          // MULTI: nearest-K selection of the current food set around the current pose
+  int nlive = 0;              // MULTI: live foods of this env, recounted whenever the food set changes
   if constexpr (LDSF) {
     load_core(e, S, P, envc);
     for (int k = 0; k < P.F; ++k) {
@@ -141,6 +153,10 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
     for (int k = P.F; k < FMAX; ++k) food.clear(k);   // the scans run over whole groups of four slots
   } else {
     load_env(e, S, P, envc);
+    if constexpr (REGF) {
+#pragma unroll
+      for (int k = 0; k < FMAX; ++k) nlive += is_none(e.fx[k]) ? 0 : 1;
+    }
   }
 
   double st_reward = 0.0;   // the one per-step statistic
@@ -156,6 +172,14 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
   // path), and that wait drains the previous step's stores on every iteration.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
+#ifdef SALP_EXP_HOIST   // experiment build: fp64 constants of the step pinned in VGPRs (salp_device.h HotK).
+  // Measured (profiles/r02/ab_notes.md session 3): -1.8 % at equal residency (~100 fewer s_mov / v_mov per
+  // step: scalar moves co-issue, they were nearly free) but 217 VGPRs cost the third wavefront per SIMD: +5 %.
+  constexpr bool kHoist = REGF && FMAX > 4;
+#else
+  constexpr bool kHoist = false;
+#endif
+  const HotK hotk = make_hotk<STD, kHoist>(P);
   const int Hrun = (rows > 0) ? H : 0;   // a wavefront past the end of the range runs zero steps
 #ifdef SALP_EXP_BLOCK_SYNC
   const bool block_full = env_begin + ((int64_t)blockIdx.x + 1) * kBlock <= env_end;
@@ -196,6 +220,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
 #else
     StepOut o;
     if constexpr (LDSF) o = step_env_lds<KMAX, FORCED, STD>(e, food, P, genv, c0, c1, K, fq, nlive);
+    else if constexpr (REGF) o = step_env_reg<FMAX, KMAX, FORCED, STD, kHoist>(e, offs, P, hotk, genv, c0, c1, K, fq, nlive);
     else o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
 #endif
     const bool done = o.terminated || o.truncated;
@@ -251,6 +276,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
               scan_foods<KMAX, false, true>(food, C.F, e.x, e.y, 0.0, fq, c_, h_, nlive);
               resolve<KMAX>(food, K, e.x, e.y, fq);
               observe_lds<KMAX, STD>(e, C, rmax, K, fq, nlive, false, 0.f, fo);
+            } else if constexpr (REGF) {
+              bool c_; int h_;
+              scan_foods_reg<FMAX, KMAX, false, true>(e, offs, C.F, 0.0, fq, c_, h_, nlive);
+              resolve_reg<KMAX>(offs, K, fq);
+              observe_lds<KMAX, STD>(e, C, rmax, K, fq, nlive, false, 0.f, fo);
             } else {
               observe<FMAX, KMAX, STD>(e, C, rmax, have_rel, o.rel, fo);
             }
@@ -282,6 +312,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 #endif
+        else if constexpr (REGF) place_food_coop_reg<FMAX, STD>(e, lane, C, genv, todo, limit);
         else place_food<FMAX, STD>(e, C, genv, todo, limit);
         todo = 0;
       }
@@ -291,11 +322,17 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
         resolve<KMAX>(food, K, e.x, e.y, fq);
         have_rel = false;
       }
+      if constexpr (REGF) {
+        bool c_; int h_;
+        scan_foods_reg<FMAX, KMAX, false, true>(e, offs, C.F, 0.0, fq, c_, h_, nlive);
+        resolve_reg<KMAX>(offs, K, fq);
+        have_rel = false;
+      }
     }
 
     if (FULL || io.obs) {
       float ob[12 + 4 * KMAX];
-      if constexpr (LDSF) observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
+      if constexpr (MULTI) observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
       else observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
 #ifdef SALP_EXP_DIRECT_STORE   // experiment: per-lane 96-B rows straight from registers (no LDS transpose)
       if (active) {
@@ -333,10 +370,16 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 4 ? 3 : (FMAX <= 
 #ifdef SALP_EXP_VMCNT
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SALP_EXP_VMCNT) : "memory");
 #elif !defined(SALP_EXP_NO_DRAIN)
-    // Drain this step's stores before the next step.  Measured (profiles/r01/ab_notes.md): letting
-    // stores run ahead (vmcnt(9)) is 2-6 % SLOWER than draining — wavefronts that stay in step keep
-    // the write stream of all CUs inside one contiguous [N x 96 B] slab at a time.
+    // One-food kernel (write-bound): drain this step's stores before the next step.  Measured
+    // (profiles/r01/ab_notes.md): letting stores run ahead (vmcnt(9)) is 2-6 % SLOWER than draining —
+    // wavefronts that stay in step keep the write stream of all CUs inside one contiguous [N x 96 B] slab
+    // at a time.  The multi-food kernels are issue-bound at 2 wavefronts per SIMD: there the drain is a
+    // stall nothing hides (-6.4 % without it, profiles/r02/ab_notes.md session 2).
+#ifdef SALP_EXP_DRAIN_ALL
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#else
+    if constexpr (!MULTI) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#endif
 #endif
 #ifdef SALP_EXP_BLOCK_SYNC
     if (block_full) __syncthreads();
