@@ -3,17 +3,23 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
-N_envs = 262144 per GPU, single_food_long_horizon parameters, random actions resident in HBM,
+Workload at --gpus 1 (BASELINE.json configs[2], the configuration the metric is quoted on):
+N_envs = 262144, single_food_long_horizon parameters, random actions resident in HBM,
 the 5000-step rollout run as K fused-rollout launches of `--chunk` steps each (defaults
 K = 20 x 250 = 5000 steps).  One bench "step" = one launch = chunk x N_envs env-steps.
 All inputs (state, actions) are resident in HBM when the timed region starts; every output
 (observations [chunk, N, 24] f32, rewards, terminated, truncated) is written to HBM.
 
-At N > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs its own shard of
-262144 envs (weak scaling) and, per launch, all-gathers the observations the step returned for
-the last step of the chunk over RCCL (`--gather final`, overlapped with the next launch;
-`--gather all` exchanges the whole block, `--gather none` nothing).
+Workload at --gpus G > 1 (launched by torch.distributed.run, one rank per GPU) = BASELINE.json
+configs[3]: N_envs = 1 048 576 IN TOTAL, sharded by env index (1048576 / G per GPU: 131072 at G = 8),
+same parameters and launches, and every launch all-gathers over RCCL the observations it returned
+(`--gather all`: the whole [chunk, N/G, 24] block of every rank, double-buffered so that the collective
+of launch k runs beside launch k + 1; this is the exchange the north_star names and it is xGMI-bound by
+construction).  The total is fixed while G grows: "scaling": "strong" (over G = 2, 4, 8).
+`--gather final` exchanges only the last step's observation of each launch (what a centralised actor
+needs to go on), `--gather none` nothing (data-parallel learners); `--weak` keeps 262144 envs per GPU
+instead (configs[2] replicated); `--envs` / `--total-envs` override the counts.  `config.workload`
+always says which configuration ran.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the fused rollout kernel against HBM
 (algorithmic bytes per env-step = act 4 + obs 96 + reward 4 + flags 2 + 2*state/H, SURVEY.md
@@ -84,15 +90,44 @@ def cpu_baseline(cfg, budget_s: float):
     }
 
 
+CONFIG2_ENVS = 262144        # BASELINE configs[2]: one GPU
+CONFIG3_TOTAL_ENVS = 1048576  # BASELINE configs[3]: sharded over the GPUs of one node
+
+
+def shard_plan(world: int, envs_per_gpu=None, total_envs=None, weak: bool = False) -> dict:
+    """Which BASELINE configuration a run of `world` ranks measures, and its split by env index.
+    Returns envs_per_gpu, total_envs, config (index into BASELINE.json configs, None for an override),
+    scaling and env_index_base(rank)."""
+    if envs_per_gpu is not None and total_envs is not None:
+        raise ValueError("give --envs (per GPU) or --total-envs, not both")
+    if envs_per_gpu is not None:
+        n, cfg_i, scaling = int(envs_per_gpu), (2 if int(envs_per_gpu) == CONFIG2_ENVS else None), "weak"
+    elif total_envs is not None:
+        if total_envs % world:
+            raise ValueError(f"--total-envs {total_envs} is not divisible by {world} ranks")
+        n, cfg_i, scaling = total_envs // world, (3 if total_envs == CONFIG3_TOTAL_ENVS and world > 1 else None), "strong"
+    elif world == 1 or weak:
+        n, cfg_i, scaling = CONFIG2_ENVS, 2, "weak"
+    else:
+        if CONFIG3_TOTAL_ENVS % world:
+            raise ValueError(f"{CONFIG3_TOTAL_ENVS} envs do not split evenly over {world} ranks; pass --total-envs")
+        n, cfg_i, scaling = CONFIG3_TOTAL_ENVS // world, 3, "strong"
+    return {"envs_per_gpu": n, "total_envs": n * world, "config": cfg_i, "scaling": scaling,
+            "env_index_base": lambda rank: rank * n}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--envs", type=int, default=262144, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: 262144 at --gpus 1, 1048576 / G at --gpus G)")
+    ap.add_argument("--total-envs", type=int, default=None, help="envs in total, split evenly over the GPUs")
+    ap.add_argument("--weak", action="store_true", help="--gpus G > 1: 262144 envs per GPU (configs[2] replicated) instead of configs[3]")
     ap.add_argument("--chunk", type=int, default=250, help="env-steps per fused rollout launch")
     ap.add_argument("--preset", default="single_food_long_horizon")
-    ap.add_argument("--gather", default="final", choices=["final", "all", "none"])
+    ap.add_argument("--gather", default=None, choices=["final", "all", "none"],
+                    help="--gpus G > 1: what each launch exchanges (default all = every returned observation)")
     ap.add_argument("--actions", default="hbm", choices=["hbm", "generated"],
                     help="hbm: a random action block resident in HBM, read by the kernel; generated: the kernel draws the "
                          "actions from each env's Philox action stream and writes them out (same 4 B per env-step)")
@@ -136,7 +171,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
 
     cfg = pkg.load_env_config(args.preset)
-    n, H, K, W = args.envs, args.chunk, args.steps, args.warmup
+    plan = shard_plan(world, args.envs, args.total_envs, args.weak)
+    n, H, K, W = plan["envs_per_gpu"], args.chunk, args.steps, args.warmup
+    gather = args.gather or "all"
 
     if world > 1 or force_sharded:
         from underwater_swimmer_rl_amd.sharded import ShardedSalpVectorEnv
@@ -153,20 +190,52 @@ def main():
         act = None      # salp_vec_rollout(act = NULL, act_out = buffer): SURVEY.md §8d config 3 "generated on device"
     rkw = {} if act is not None else {"horizon": H}
 
-    def one_launch():
+    # --gather all: two output blocks, so that the collective of launch k (which reads block k % 2) runs beside
+    # launch k + 1 (which writes the other one); a block is only rewritten after its collective has completed
+    outs, works = [None, None], [None, None]
+    if senv is not None and gather == "all":
+        assert senv.env_index_base == plan["env_index_base"](rank) and senv.local_envs == n
+        for b in range(2):
+            outs[b] = dict(obs=torch.empty((H, n, cfg.obs_dim), device=device), reward=torch.empty((H, n), device=device),
+                           terminated=torch.empty((H, n), dtype=torch.uint8, device=device),
+                           truncated=torch.empty((H, n), dtype=torch.uint8, device=device))
+
+    def sharded_launch(k):
+        if gather == "all":
+            b = k & 1
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
+            out = senv.engine.rollout(act, out=outs[b], **rkw)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            _, works[b] = senv.all_gather(f"all_obs{b}", out["obs"].reshape(1, H, n, cfg.obs_dim), async_op=True)
+            return ev
+        out = senv.engine.rollout(act, **rkw)
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if gather == "final":   # staged + double-buffered: the next launch starts at once, the collective runs beside it
+            senv.gather_final_async(out["obs"][-1])
+        return ev
+
+    def drain():
+        for b in range(2):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
         if senv is not None:
-            senv.rollout(act, gather=args.gather, async_gather=True, **rkw)
+            senv.wait_gather()
+
+    for k in range(W):
+        if senv is not None:
+            sharded_launch(k)
         else:
             env.rollout(act, **rkw)
-
-    for _ in range(W):
-        one_launch()
-    if senv is not None:
-        senv.wait_gather()
+    drain()
     env.clear_stats()
 
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
+    ends = [None] * K
     torch.cuda.synchronize(device)
     if senv is not None:
         dist.barrier()
@@ -175,19 +244,12 @@ def main():
     for k in range(K):
         starts[k].record()
         if senv is not None:
-            out = senv.engine.rollout(act, **rkw)
-            ends[k].record()
-            if args.gather == "final":
-                # staged + double-buffered: the next launch starts at once, the collective runs beside it
-                senv.gather_final_async(out["obs"][-1])
-            elif args.gather == "all":
-                g, work = senv.all_gather("all_obs", out["obs"].reshape(1, H, n, cfg.obs_dim), async_op=True)
-                work.wait()                  # the block is overwritten by the next launch: xGMI-bound by construction
+            ends[k] = sharded_launch(k)
         else:
             env.rollout(act, **rkw)
+            ends[k] = torch.cuda.Event(enable_timing=True)
             ends[k].record()
-    if senv is not None:
-        senv.wait_gather()
+    drain()
     torch.cuda.synchronize(device)
     if senv is not None:
         dist.barrier()
@@ -223,12 +285,19 @@ def main():
     line = {
         "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": plan["scaling"], "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[2]: N_envs={n}/GPU {args.preset}, {H * K}-step rollout as {K} fused launches of {H} steps, " +
-                        ("random actions in HBM" if act is not None else "random actions drawn in the kernel and written out"),
+            "workload": (f"BASELINE configs[{plan['config']}]" if plan["config"] is not None else "override (not a BASELINE config)") +
+                        f": N_envs={plan['total_envs']} total = {n}/GPU x {world}, {args.preset}, {H * K}-step rollout as {K} fused "
+                        f"launches of {H} steps, " +
+                        ("random actions in HBM" if act is not None else "random actions drawn in the kernel and written out") +
+                        ("" if senv is None else {"all": ", every launch all-gathers ALL observations it returned ([chunk, N/G, obs_dim] per rank) over RCCL",
+                                                  "final": ", every launch all-gathers the LAST step's observation over RCCL",
+                                                  "none": ", no exchange"}[gather]),
+            "baseline_config": plan["config"], "total_envs": plan["total_envs"],
             "envs_per_gpu": n, "chunk": H, "obs_dim": cfg.obs_dim, "act_dim": cfg.act_dim,
-            "parallelism": f"env-sharded x{world}" + (f", all-gather {args.gather} obs" if senv is not None else ""),
+            "gather": gather if senv is not None else None,
+            "parallelism": f"env-sharded x{world}" + (f", all-gather {gather} obs" if senv is not None else ""),
             "env_steps_per_bench_step": n * H * world,
         },
         "roofline": {

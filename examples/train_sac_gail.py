@@ -58,13 +58,13 @@ def main():
             last = agent.update(buf.sample(cfg.batch_size))
         obs = nobs.clone()
         if args.log_every and (step + 1) % args.log_every == 0:
-            print(f"[sac+gail] step {step + 1} D acc {dlast.get('discriminator_accuracy', float('nan')):.3f} "
+            print(f"[sac+gail] step {step + 1} D acc {float(dlast.get('discriminator_accuracy', float('nan'))):.3f} "
                   f"critic {float(last.get('critic_loss', float('nan'))):.3f}", flush=True)
     torch.cuda.synchronize()
     out = {"wall_s": time.perf_counter() - t0, "vector_steps": args.steps, "env_steps": args.steps * args.envs,
            "first_food_wall_s": first_food[0] if first_food else None,
            "first_food_vector_step": first_food[1] if first_food else None, "expert_pairs": len(experts),
-           "discriminator": dlast, "sac": {k: float(v) for k, v in last.items()}, "stats": env.stats()}
+           "discriminator": Discriminator.metrics_to_host(dlast) if dlast else {}, "sac": {k: float(v) for k, v in last.items()}, "stats": env.stats()}
     print(json.dumps(out))
     env.close()
 

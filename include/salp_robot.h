@@ -13,6 +13,10 @@
  *
  * Actions are float32 [n][3] in the env's Box ([0,1], [0,1], [-1,1]): contraction / 0.06 m, coast time
  * / 10 s, nozzle yaw / (pi/2).  They are widened to fp64 before the rescale of salp_robot_env.py:129-137.
+ * The reference does not clip them, and neither does this library, with one exception: the length of a
+ * breathing cycle (refill + jet + coast, 14.5 s at most inside the Box) is cut at 14.6 s, and a non-finite
+ * length runs no Euler step — one out-of-Box or inf action must not spin a wavefront of 64 robots for ever
+ * (the reference would stall that one CPU env for the corresponding number of Euler steps).
  * Observation float32 [n][6]: x - target_x, y - target_y, body-frame vx, vy, yaw, yaw rate (:400-420).
  * Same conventions as salp_vec.h (status codes, SALP_DEVICE_PTRS, streams, same-step autoreset).
  * The target point of each episode (np.random.uniform, :247-250) comes from

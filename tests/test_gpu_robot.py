@@ -60,6 +60,32 @@ def test_hip_robot_matches_oracle_on_a_batch():
     orc.close()
 
 
+def test_out_of_box_and_non_finite_actions_return_promptly():
+    """An unsquashed policy output must not spin the kernel: a cycle longer than the action Box allows is cut at
+    14.6 s (<= 1460 Euler steps of 0.01 s), a non-finite one runs no Euler step (include/salp_robot.h)."""
+    import time
+    import torch
+    n = 256
+    env = SalpRobotVectorEnv(n, device="cuda:0", seed=3)
+    a = np.tile(np.array([0.5, 0.1, 0.0], np.float32), (n, 1))
+    a[0] = (1.0e9, 1.0e9, 0.0)
+    a[1] = (0.5, np.inf, 0.0)
+    a[2] = (np.inf, 0.0, 0.0)
+    a[3] = (np.nan, np.nan, np.nan)
+    a[4] = (0.5, -np.inf, 0.0)
+    t0 = time.time()
+    obs, rew, term, trunc, info = env.step(a)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 5.0
+    steps = info["inner_steps"].cpu().numpy()
+    assert steps.max() <= 1461 and steps[0] >= 1459 and steps[1] >= 1459
+    assert steps[3] == 0 and steps[4] == 0
+    assert np.isfinite(obs.cpu().numpy()[5:]).all()
+    obs, rew, term, trunc, info = env.step(np.tile(np.array([0.5, 0.1, 0.0], np.float32), (n, 1)))   # still alive
+    torch.cuda.synchronize()
+    env.close()
+
+
 def test_cycle_length_schedule_does_not_change_results(monkeypatch):
     """The longest-cycle-first walk order (salp_robot.hip, robot_schedule_*) only moves envs between lanes:
     with it forced on and forced off every output and the final state are bit-identical."""

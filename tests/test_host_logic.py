@@ -78,6 +78,25 @@ def test_bench_roofline_accounting():
     assert bench.algorithmic_bytes_per_env_step(pkg.load_env_config("sac_gail"), 1) == 394.0
 
 
+def test_bench_shard_plan_is_baseline_configs_2_and_3():
+    """bench.py --gpus 1 measures BASELINE configs[2] (262144 envs), --gpus G > 1 configs[3]: 1 048 576 envs in total,
+    split by contiguous env-index blocks (131072 per GPU at G = 8, env_index_base = rank * 131072)."""
+    import bench
+    p1 = bench.shard_plan(1)
+    assert (p1["envs_per_gpu"], p1["total_envs"], p1["config"], p1["scaling"]) == (262144, 262144, 2, "weak")
+    for g, per in ((2, 524288), (4, 262144), (8, 131072)):
+        p = bench.shard_plan(g)
+        assert (p["envs_per_gpu"], p["total_envs"], p["config"], p["scaling"]) == (per, 1048576, 3, "strong")
+        assert [p["env_index_base"](r) for r in range(g)] == [r * per for r in range(g)]
+    pw = bench.shard_plan(8, weak=True)
+    assert (pw["envs_per_gpu"], pw["total_envs"], pw["config"], pw["scaling"]) == (262144, 8 * 262144, 2, "weak")
+    assert bench.shard_plan(2, total_envs=32768)["config"] is None          # an override is labelled as such
+    with pytest.raises(ValueError):
+        bench.shard_plan(3)                                                   # 1048576 does not split over 3 ranks
+    with pytest.raises(ValueError):
+        bench.shard_plan(2, envs_per_gpu=8, total_envs=16)
+
+
 def test_adaptive_food_curriculum_follows_the_reference_rule():
     """continuous_trainer.py:375-415: window of 10 episodes, > 0.6 removes a food, < 0.25 adds one, within [2, 12],
     window cleared after a change; the change is the base_num_food_items write."""

@@ -78,9 +78,12 @@ def test_discriminator_separates_expert_from_agent_and_rewards_follow():
     assert m["discriminator_accuracy"] > 0.95
     r_exp = d.predict_reward(torch.full((8, 6), 1.0), torch.full((8, 1), 0.8))
     r_agt = d.predict_reward(torch.full((8, 6), -1.0), torch.full((8, 1), -0.8))
-    assert r_exp.shape == (8,) and float(r_exp.mean()) > float(r_agt.mean()) + 1.0
+    assert r_exp.shape == (8, 1) and float(r_exp.mean()) > float(r_agt.mean()) + 1.0      # [B, 1] as the reference
     mix = gail_reward_fn(d)(torch.full((8, 6), 1.0), torch.full((8, 1), 0.8), torch.ones(8))
-    assert torch.allclose(mix, 0.3 * torch.ones(8) + 0.7 * r_exp)
+    assert mix.shape == (8,) and torch.allclose(mix, 0.3 * torch.ones(8) + 0.7 * r_exp.squeeze(-1))
+    host = Discriminator.metrics_to_host(m)
+    assert set(host) == {"discriminator_loss", "expert_loss", "agent_loss", "discriminator_accuracy",
+                         "expert_prob_mean", "agent_prob_mean"} and all(isinstance(v, float) for v in host.values())
 
 
 def test_agent_presets_restate_the_yaml_agent_blocks():
@@ -103,7 +106,7 @@ def test_sac_trains_on_the_hip_vector_env():
     assert m["env_steps"] == 60 * 1024 and m["updates"] == 80
     assert all(math.isfinite(m[k]) for k in ("critic_loss", "actor_loss", "alpha"))
     d = disc.update(eb.sample(128), {"observations": env.observe().clone(), "actions": agent.act(env.observe())})
-    assert math.isfinite(d["discriminator_loss"])
+    assert math.isfinite(float(d["discriminator_loss"]))
     env.close()
 
 

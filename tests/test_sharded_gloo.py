@@ -28,8 +28,12 @@ class OracleEngine:
         return self.o.reset(), {}
 
     def step(self, actions):
-        out = self.o.step(np.asarray(actions, np.float32))
-        return out["obs"], out["reward"], out["terminated"].astype(bool), out["truncated"].astype(bool), {}
+        out = self.o.step(np.asarray(actions, np.float32), want_final=True)
+        done = (out["terminated"] | out["truncated"]).astype(bool)
+        fin = np.where(done[:, None], out["final_obs"], 0.0).astype(np.float32)   # rows of unfinished envs: unspecified
+        info = {"food_collected": out["info"][:, 0], "steps_since_food": out["info"][:, 1], "collision": out["info"][:, 2],
+                "final_observation": fin, "_final_observation": done}
+        return out["obs"], out["reward"], out["terminated"].astype(bool), out["truncated"].astype(bool), info
 
     def rollout(self, actions=None, horizon=None):
         a = None if actions is None else np.asarray(actions, np.float32)
@@ -61,10 +65,14 @@ def _worker(rank, world, port, tmp):
         obs0, _ = env.reset()
         obs0 = obs0.clone()                 # gathered tensors are reused buffers (valid until the next call)
         steps = []
-        for t in range(40):
-            g_obs, g_rew, g_term, g_trunc, _ = env.step(torch.from_numpy(act[t]))
-            steps.append((g_obs.numpy().copy(), g_rew.numpy().copy(), g_term.numpy().copy(), g_trunc.numpy().copy()))
-        local, g_final = env.rollout(torch.from_numpy(act[40:]), gather="final")
+        for t in range(70):
+            g_obs, g_rew, g_term, g_trunc, g_info = env.step(torch.from_numpy(act[t]))
+            assert g_info["final_observation"].shape == (N, cfg.obs_dim) and g_info["food_collected"].shape == (N,)
+            assert torch.equal(g_info["_final_observation"], g_term | g_trunc)
+            steps.append((g_obs.numpy().copy(), g_rew.numpy().copy(), g_term.numpy().copy(), g_trunc.numpy().copy(),
+                          g_info["final_observation"].numpy().copy(), g_info["food_collected"].numpy().copy(),
+                          g_info["steps_since_food"].numpy().copy(), g_info["collision"].numpy().copy()))
+        local, g_final = env.rollout(torch.from_numpy(act[70:]), gather="final")
         _, g_all = env.rollout(torch.from_numpy(act[:10]), gather="all", async_gather=True)
         env.wait_gather()
         _, g_none = env.rollout(torch.from_numpy(act[:5]), gather="none")
@@ -82,7 +90,8 @@ def _worker(rank, world, port, tmp):
                 asy.append(g.numpy().copy())      # launch 2 went through slot 0 again
         np.savez(os.path.join(tmp, f"rank{rank}.npz"), obs0=obs0.numpy(), g_final=g_final.numpy(), g_all=g_all.numpy(),
                  g_async1=asy[0], g_async2=asy[1],
-                 **{f"s{t}_{k}": v for t, s in enumerate(steps) for k, v in zip(("obs", "rew", "term", "trunc"), s)})
+                 **{f"s{t}_{k}": v for t, s in enumerate(steps)
+                    for k, v in zip(("obs", "rew", "term", "trunc", "fin", "fc", "ssf", "coll"), s)})
         env.close()
     finally:
         dist.destroy_process_group()
@@ -102,12 +111,20 @@ def test_two_rank_sharding_equals_single_process(tmp_path):
     act = np.random.default_rng(0).uniform(-1, 1, size=(H, N, 1)).astype(np.float32)
     one = ol.OracleVec(cfg, N, seed=seed)
     assert np.array_equal(r0["obs0"], one.reset())          # reset() draws new food, as snake:133-155 does
-    for t in range(40):
-        out = one.step(act[t])
+    finished = 0
+    for t in range(70):
+        out = one.step(act[t], want_final=True)
         assert np.array_equal(r0[f"s{t}_obs"], out["obs"]) and np.array_equal(r0[f"s{t}_rew"], out["reward"])
         assert np.array_equal(r0[f"s{t}_term"], out["terminated"].astype(bool))
         assert np.array_equal(r0[f"s{t}_trunc"], out["truncated"].astype(bool))
-    out = one.rollout(act[40:])
+        # the gathered info is the unsharded engine's: counters of every env, terminal observation of finished ones
+        assert np.array_equal(r0[f"s{t}_fc"], out["info"][:, 0]) and np.array_equal(r0[f"s{t}_ssf"], out["info"][:, 1])
+        assert np.array_equal(r0[f"s{t}_coll"], out["info"][:, 2])
+        done = (out["terminated"] | out["truncated"]).astype(bool)
+        finished += int(done.sum())
+        assert np.array_equal(r0[f"s{t}_fin"][done], out["final_obs"][done])
+    assert finished > 0                                                        # envs of both halves finished (truncation at step 61) in the stepped part
+    out = one.rollout(act[70:])
     assert out["truncated"].sum() > 0                                         # resets happened inside the shard
     assert np.array_equal(r0["g_final"], out["obs"][-1])
     out = one.rollout(act[:10])

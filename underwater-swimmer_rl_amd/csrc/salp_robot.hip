@@ -202,6 +202,7 @@ __global__ __launch_bounds__(kRBlock) void salp_robot_reset_kernel(RobotParams P
 // Blocks of 1024 envs histogram in LDS first, so a block makes at most one global atomic per bin
 // (one global atomic per env measured 45 us per pass at 262144 envs, 7 % of the step).
 constexpr int kSchedBins = 256;
+constexpr double kMaxCycleTime = 14.6;   // s; an in-Box action asks for at most 0.06 * (3 + 1.5) / 0.06 + 10 = 14.5 s
 constexpr int kSchedBlock = 1024;
 
 __device__ __forceinline__ int schedule_bin(const RobotParams& P, const float* act, int64_t i) {
@@ -313,7 +314,13 @@ void salp_robot_step_kernel(RobotParams P, RobotState S, const float* act, float
   const double contract_rate = 0.06 / 3, release_rate = 0.06 / 1.5;
   const double refill_time = contraction / contract_rate;
   const double jet_time = contraction / release_rate;
-  const double total = active ? refill_time + jet_time + coast_time : 0.0;   // padding lanes do not step
+  // The cycle length comes straight from the caller's action.  Inside the action Box [0, 1]^3 it is at most
+  // 0.06 * 75 + 10 = 14.5 s; the device loop below is bounded by that maximum (kMaxCycleTime), so an unsquashed
+  // or diverged policy output (1e9, +inf) cannot spin a wavefront for ever — the reference would stall ONE CPU
+  // env for the corresponding 1e11 Euler steps; here a cycle longer than the Box allows is cut at the Box
+  // maximum (include/salp_robot.h).  A non-finite length runs no Euler step at all.
+  double total = active ? refill_time + jet_time + coast_time : 0.0;   // padding lanes do not step
+  total = (total <= kMaxCycleTime) ? total : ((total > kMaxCycleTime) ? kMaxCycleTime : 0.0);
   double cycle_time = 0.0;
   int steps = 0;
   const double dt = P.dt;

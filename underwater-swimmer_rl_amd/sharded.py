@@ -32,7 +32,7 @@ def _to_tensor(x, device):
 class ShardedSalpVectorEnv:
     def __init__(self, config="single_food", num_envs: int = 8 * 131072, *, process_group=None,
                  device: Optional[str] = None, seed: int = 0, engine_factory: Optional[Callable] = None,
-                 **overrides):
+                 gather_final_observation: bool = True, **overrides):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend 'nccl' on GPUs)")
         self.pg = process_group
@@ -53,6 +53,18 @@ class ShardedSalpVectorEnv:
             self.engine = engine_factory(self.cfg, self.local_envs, seed, self.env_index_base)
             self.device = torch.device("cpu")
         self.obs_dim, self.act_dim = self.cfg.obs_dim, self.cfg.act_dim
+        self.gather_final_observation = bool(gather_final_observation)
+        # all_gather_into_tensor is the one flat collective RCCL runs; a backend without it (older gloo) is
+        # found ONCE here, by its NotImplementedError on a probe — never by catching errors of a real exchange
+        # (an RCCL failure must surface, not be retried on a poisoned communicator).
+        self._flat_gather = True
+        if dist.get_backend(self.pg) != "nccl":
+            probe_in = torch.zeros(1, device=self.device)
+            probe_out = torch.zeros(self.world, device=self.device)
+            try:
+                dist.all_gather_into_tensor(probe_out, probe_in, group=self.pg)
+            except NotImplementedError:
+                self._flat_gather = False
         self._pending = []
         self._gbuf = {}
         self._pack = None
@@ -71,9 +83,9 @@ class ShardedSalpVectorEnv:
         """Concatenates every rank's block along dim 0 (rank order = env order)."""
         local = _to_tensor(local, self.device).contiguous()
         out = self._out(name, local)
-        try:
+        if self._flat_gather:
             work = dist.all_gather_into_tensor(out, local, group=self.pg, async_op=async_op)
-        except (RuntimeError, NotImplementedError):
+        else:
             chunks = list(out.chunk(self.world, dim=0))
             work = dist.all_gather(chunks, local, group=self.pg, async_op=async_op)
         return (out, work) if async_op else out
@@ -98,22 +110,41 @@ class ShardedSalpVectorEnv:
         return self.all_gather("obs", obs), info
 
     def step(self, actions):
-        """Every rank returns the full [N, ...] batch (obs, reward, terminated, truncated).  One collective per
-        step: observation, reward and the two flags travel as one [N/G, obs_dim + 2] float32 block (a ring
-        all-gather over xGMI is latency-bound at this size; three separate ones cost three launches)."""
+        """Every rank returns the full [N, ...] batch: obs, reward, terminated, truncated AND info — `info` holds
+        global `food_collected`, `steps_since_food`, `collision` [N] and (unless the env was built with
+        gather_final_observation=False) `final_observation` [N, obs_dim] with its mask `_final_observation`,
+        so the consumer pattern of the single-GPU env (`torch.where(done[:, None], info["final_observation"],
+        obs)`) bootstraps from the true terminal observation of every shard.  One collective per step: all of
+        it travels as one [N/G, W] float32 block, W = obs_dim + 5 (+ obs_dim with terminal observations) — a
+        ring all-gather over xGMI is latency-bound at this size, separate collectives cost one launch each.
+        (The three info columns are small non-negative integers: exact in float32.)"""
         a = self._shard(actions, 0)
         obs, rew, term, trunc, info = self.engine.step(a)
+        D = self.obs_dim
         obs, rew = _to_tensor(obs, self.device), _to_tensor(rew, self.device)
         flags = _to_tensor(term, self.device).to(torch.float32) + 2.0 * _to_tensor(trunc, self.device).to(torch.float32)
+        fin = info.get("final_observation") if self.gather_final_observation else None
+        W = D + 5 + (D if fin is not None else 0)
         pack = self._pack
-        if pack is None or pack.shape[0] != obs.shape[0] or pack.device != obs.device:
-            pack = self._pack = torch.empty((obs.shape[0], self.obs_dim + 2), dtype=torch.float32, device=obs.device)
-        pack[:, :self.obs_dim] = obs
-        pack[:, self.obs_dim] = rew
-        pack[:, self.obs_dim + 1] = flags
+        if pack is None or tuple(pack.shape) != (obs.shape[0], W) or pack.device != obs.device:
+            pack = self._pack = torch.zeros((obs.shape[0], W), dtype=torch.float32, device=obs.device)
+        pack[:, :D] = obs
+        pack[:, D] = rew
+        pack[:, D + 1] = flags
+        for j, k in enumerate(("food_collected", "steps_since_food", "collision")):
+            if k in info:
+                pack[:, D + 2 + j] = _to_tensor(info[k], self.device).to(torch.float32)
+        if fin is not None:
+            pack[:, D + 5:] = _to_tensor(fin, self.device)
         g = self.all_gather("step", pack)
-        gf = g[:, self.obs_dim + 1]
-        return g[:, :self.obs_dim], g[:, self.obs_dim], (gf == 1.0) | (gf == 3.0), gf >= 2.0, info
+        gf = g[:, D + 1]
+        g_term, g_trunc = (gf == 1.0) | (gf == 3.0), gf >= 2.0
+        ginfo = {"food_collected": g[:, D + 2].to(torch.int32), "steps_since_food": g[:, D + 3].to(torch.int32),
+                 "collision": g[:, D + 4].to(torch.int32), "local": info}
+        if fin is not None:
+            ginfo["final_observation"] = g[:, D + 5:]
+            ginfo["_final_observation"] = g_term | g_trunc
+        return g[:, :D], g[:, D], g_term, g_trunc, ginfo
 
     def rollout(self, actions=None, horizon=None, gather: str = "final", async_gather: bool = False):
         """Local fused rollout of `horizon` steps, then the exchange:

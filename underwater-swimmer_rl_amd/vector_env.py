@@ -168,8 +168,9 @@ class SalpVectorEnv:
             self._prepare_step()
             c = self._step_cache
         t = self._torch
-        if t is not None and isinstance(actions, t.Tensor) and actions.is_cuda and actions.dtype == t.float32 \
-                and actions.is_contiguous() and actions.numel() == self.num_envs * self.act_dim:
+        if t is not None and isinstance(actions, t.Tensor) and actions.is_cuda and actions.device == self.device \
+                and actions.dtype == t.float32 and actions.is_contiguous() \
+                and actions.numel() == self.num_envs * self.act_dim:
             a = actions
             p_act = c["vp"](a.data_ptr())
             stream = c["vp"](t.cuda.current_stream(self.device).cuda_stream)
