@@ -90,6 +90,29 @@ def cpu_baseline(cfg, budget_s: float):
     }
 
 
+def sac_first_capture(device, world: int, rank: int, envs: int = 4096, max_steps: int = 600):
+    """BASELINE configs[4], outside the timed region and bounded to a few seconds: SAC with the agent block of
+    configs/sac_gail.yaml on the HIP VectorEnv (sac_gail preset, `envs` envs per GPU, one hipGraph replay per
+    vector step; at world > 1 one replica per rank, gradients all-reduced between graph segments) until any env
+    collects its first food.  Returns wall-clock seconds and vector steps; never raises (a failure is recorded)."""
+    try:
+        import underwater_swimmer_rl_amd as pkg
+        from underwater_swimmer_rl_amd.sac import SAC, SACConfig, train_sac_graphed
+        env = pkg.SalpVectorEnv("sac_gail", num_envs=envs, device=str(device), seed=0, env_index_base=rank * envs)
+        cfg = SACConfig.from_preset("sac_gail")
+        cfg.learning_starts = 50
+        agent = SAC(env.obs_dim, env.act_dim, cfg, device=str(device), seed=0, data_parallel=world > 1,
+                    act_low=env.single_action_space.low, act_high=env.single_action_space.high)
+        m = train_sac_graphed(env, agent, max_steps, stop_at_first_food=True)
+        env.close()
+        return {"seconds": m["first_food_wall_s"], "vector_steps": m["first_food_vector_step"], "envs_per_gpu": envs,
+                "n_gpus": world, "mode": "hipgraph, segmented + RCCL gradient all-reduce" if world > 1 else "hipgraph",
+                "updates": m["updates"], "learn_ms_per_vector_step": m["learn_ms_per_vector_step"],
+                "note": "includes graph capture and 3 eager warm-up iterations per phase; outside the timed region"}
+    except Exception as e:   # noqa: BLE001 — the bench line must not be lost to the probe
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 CONFIG2_ENVS = 262144        # BASELINE configs[2]: one GPU
 CONFIG3_TOTAL_ENVS = 1048576  # BASELINE configs[3]: sharded over the GPUs of one node
 
@@ -133,6 +156,7 @@ def main():
                          "actions from each env's Philox action stream and writes them out (same 4 B per env-step)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sac-probe", action="store_true", help="skip the configs[4] first-food-capture probe")
     args = ap.parse_args()
 
     import torch
@@ -308,6 +332,9 @@ def main():
         },
         "episodes_finished": stats["episodes"], "food_collected": stats["food_collected"],
     }
+    if not args.no_sac_probe and not rehearsal and not force_sharded:
+        probe = sac_first_capture(device, world if senv is not None else 1, rank)   # every rank takes part (collectives)
+        line["sac_first_capture"] = probe
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
     elif rank == 0:

@@ -3,8 +3,8 @@
 VectorEnv; reports the wall-clock to the first food capture.  One GPU:
     python examples/train_sac.py --envs 4096 --steps 2000
 Data-parallel over the GPUs of one node (one env shard, replay buffer and learner replica per rank, gradients
-averaged over RCCL):
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_sac.py --eager"""
+averaged over RCCL between the hipGraph segments of an iteration):
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_sac.py"""
 import argparse
 import json
 import os
@@ -34,7 +34,6 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", device_id=torch.device(dev))
-        args.eager = True                      # the captured loop is single-process
     # --envs is per GPU; global env indices keep every env's draw stream distinct across ranks
     env = salp.SalpVectorEnv(args.preset, num_envs=args.envs, device=dev, seed=0, env_index_base=rank * args.envs)
     cfg = SACConfig.from_preset(args.preset)

@@ -162,3 +162,44 @@ def test_graphed_sac_training_runs_and_counts_like_the_eager_loop():
     assert all(np.isfinite(m[k]) for k in ("critic_loss", "actor_loss", "alpha", "entropy"))
     assert any(not torch.equal(a, b) for a, b in zip(w0, agent.actor.parameters()))
     env.close()
+
+
+@pytest.mark.gpu
+def test_configs4_first_food_capture_with_the_yaml_agent_block():
+    """BASELINE configs[4] on one GPU: SAC with configs/sac_gail.yaml's agent block (SACConfig.from_preset) on 4096
+    envs of the sac_gail preset, one hipGraph replay per vector step, fixed seeds: some env captures its first food
+    within a few hundred vector steps (164 when DESIGN.md §8 was written); wall-clock is reported, not asserted."""
+    import json
+    from underwater_swimmer_rl_amd.sac import train_sac_graphed
+    env = pkg.SalpVectorEnv("sac_gail", num_envs=4096, device="cuda:0", seed=0)
+    cfg = SACConfig.from_preset("sac_gail")
+    cfg.learning_starts = 50
+    agent = SAC(env.obs_dim, env.act_dim, cfg, device="cuda:0", seed=0,
+                act_low=env.single_action_space.low, act_high=env.single_action_space.high)
+    m = train_sac_graphed(env, agent, 600, stop_at_first_food=True)
+    print("configs[4] first capture:", json.dumps({k: m[k] for k in ("first_food_vector_step", "first_food_wall_s", "wall_s", "vector_steps")}))
+    assert m["first_food_vector_step"] is not None and 1 <= m["first_food_vector_step"] <= 400
+    assert m["first_food_wall_s"] is not None and m["first_food_wall_s"] < 60.0
+    assert env.stats()["food_collected"] >= 1
+    env.close()
+
+
+@pytest.mark.gpu
+def test_segmented_graph_iteration_trains_like_the_single_graph():
+    """The data-parallel form of the captured loop (graph segments with the gradient all-reduces between them), forced
+    at world size 1: same number of updates, finite losses, and — the all-reduce being the identity at world size 1 —
+    the same first-capture step as the single-graph loop from the same seeds."""
+    from underwater_swimmer_rl_amd.sac import train_sac_graphed
+    out = []
+    for seg in (False, True):
+        env = pkg.SalpVectorEnv("sac_gail", num_envs=1024, device="cuda:0", seed=0)
+        cfg = SACConfig.from_preset("sac_gail")
+        cfg.learning_starts, cfg.updates_per_step = 20, 2
+        agent = SAC(env.obs_dim, env.act_dim, cfg, device="cuda:0", seed=0)
+        m = train_sac_graphed(env, agent, 80, force_segments=seg)
+        assert m["segmented"] is seg and m["updates"] == 2 * 60
+        assert all(math.isfinite(m[k]) for k in ("critic_loss", "actor_loss", "alpha", "entropy"))
+        assert m["graphs"] == (2 if not seg else 1 + (1 + 2 * 2))       # random phase: 1; learning phase: 1 or 1 + 2 x updates
+        out.append(m)
+        env.close()
+    assert out[0]["env_steps"] == out[1]["env_steps"] == 80 * 1024

@@ -209,6 +209,7 @@ class SAC:
         self.target_entropy = -float(act_dim) if cfg.target_entropy is None else float(cfg.target_entropy)
         self.updates = 0
         self.world = 1
+        self.exchange = False      # gradients go through the flat exchange buffers (world > 1, or forced by a test)
         if self.data_parallel:
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -221,29 +222,54 @@ class SAC:
                     dist.broadcast(t, src=src, group=self.pg)
             if seed is not None:    # same weights everywhere, different exploration noise per replica
                 torch.manual_seed(seed + 1 + dist.get_rank(self.pg))
+            self.exchange = self.world > 1
 
-    def _average_grads(self, params):
-        """One all-reduce for the whole network (a few hundred KB: a single bucket is the right size for
-        xGMI's per-link ring), then the mean."""
+    # ------------------------------------------------------------------ one update = three capturable stages
+    # An update has two points where data-parallel replicas must exchange gradients (after the critic's backward,
+    # after the actor's / entropy coefficient's).  It is therefore written as three stages with NO collective
+    # inside: `update()` runs them back to back with the all-reduces in between, and `train_sac_graphed` captures
+    # each stage into its own hipGraph segment and issues the all-reduces between the replays — the whole
+    # iteration stays graph-replayed on every rank (at world size 1 the three stages are one graph).
+    # What crosses a stage boundary lives in persistent tensors (`_flat_*`, `_carry`), never in autograd state.
+    def _flat_for(self, name, params):
+        n = sum(p.numel() for p in params)
+        f = getattr(self, name, None)
+        if f is None or f.numel() != n:
+            f = torch.zeros(n, device=self.device)
+            setattr(self, name, f)
+        return f
+
+    @staticmethod
+    def _pack(flat, params):
+        torch.cat([p.grad.reshape(-1) for p in params], out=flat)
+
+    @staticmethod
+    def _unpack(flat, params):
+        o = 0
+        for p in params:
+            n = p.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p))
+            o += n
+
+    def _all_reduce_mean(self, flat):
+        """One all-reduce for a whole network (a few hundred KB: a single bucket is the right size for xGMI's
+        per-link ring), then the mean.  Eager: called between graph segments."""
         if self.world == 1:
             return
         import torch.distributed as dist
-        grads = [p.grad for p in params if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat, group=self.pg)
         flat.div_(self.world)
-        o = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[o:o + n].view_as(g))
-            o += n
 
-    @torch.no_grad()
-    def act(self, obs, deterministic=False):
-        a, _ = self.actor(obs, deterministic=deterministic, with_logprob=False)
-        return a
+    def _carry_set(self, **kw):
+        c = self.__dict__.setdefault("_carry", {})
+        for k, v in kw.items():
+            if k in c and c[k].shape == v.shape:
+                c[k].copy_(v)
+            else:
+                c[k] = v.detach().clone()
 
-    def update(self, batch) -> Dict[str, torch.Tensor]:
+    def stage_critic(self, batch):
+        """Twin-critic loss and backward; leaves the flat critic gradient in `_flat_c`."""
         obs, act, rew, next_obs, term = batch
         alpha = self.log_alpha.exp().detach()
         with torch.no_grad():
@@ -254,30 +280,63 @@ class SAC:
         critic_loss = 0.5 * (F.mse_loss(q1, target) + F.mse_loss(q2, target))
         self.critic_opt.zero_grad(set_to_none=True)
         critic_loss.backward()
-        self._average_grads(list(self.critic.parameters()))
-        self.critic_opt.step()
+        self._carry_set(obs=obs, critic_loss=critic_loss)
+        if self.exchange:
+            self._cparams = list(self.critic.parameters())
+            self._pack(self._flat_for("_flat_c", self._cparams), self._cparams)
 
+    def stage_actor(self):
+        """Critic step (with the averaged gradient), then actor / entropy-coefficient losses and backward; leaves
+        their flat gradient in `_flat_a`."""
+        if self.exchange:
+            self._unpack(self._flat_c, self._cparams)
+        self.critic_opt.step()
+        obs = self._carry["obs"]
+        alpha = self.log_alpha.exp().detach()
         pa, logp = self.actor(obs)
         pq1, pq2 = self.critic(obs, pa)
         actor_loss = (alpha * logp - torch.min(pq1, pq2)).mean()
         self.actor_opt.zero_grad(set_to_none=True)
         actor_loss.backward()
-        self._average_grads(list(self.actor.parameters()))
-        self.actor_opt.step()
-
         if self.learn_alpha:
             alpha_loss = -(self.log_alpha * (logp.detach() + self.target_entropy).mean())
             self.alpha_opt.zero_grad(set_to_none=True)
             alpha_loss.backward()
-            self._average_grads([self.log_alpha])
+        self._carry_set(actor_loss=actor_loss, entropy=-logp.detach().mean())
+        if self.exchange:
+            self._aparams = list(self.actor.parameters()) + ([self.log_alpha] if self.learn_alpha else [])
+            self._pack(self._flat_for("_flat_a", self._aparams), self._aparams)
+
+    def stage_finish(self) -> Dict[str, torch.Tensor]:
+        """Actor and entropy-coefficient steps, polyak update of the target critic."""
+        if self.exchange:
+            self._unpack(self._flat_a, self._aparams)
+        self.actor_opt.step()
+        if self.learn_alpha:
             self.alpha_opt.step()
         with torch.no_grad():  # polyak update (core/base_agent.py:63-74 soft_update), two multi-tensor kernels
             tps, ps = list(self.critic_target.parameters()), list(self.critic.parameters())
             torch._foreach_mul_(tps, 1.0 - self.cfg.tau)
             torch._foreach_add_(tps, ps, alpha=self.cfg.tau)
+        c = self._carry
+        return {"critic_loss": c["critic_loss"], "actor_loss": c["actor_loss"],
+                "alpha": self.log_alpha.exp().detach(), "entropy": c["entropy"]}
+
+    @torch.no_grad()
+    def act(self, obs, deterministic=False):
+        a, _ = self.actor(obs, deterministic=deterministic, with_logprob=False)
+        return a
+
+    def update(self, batch) -> Dict[str, torch.Tensor]:
+        self.stage_critic(batch)
+        if self.exchange:
+            self._all_reduce_mean(self._flat_c)
+        self.stage_actor()
+        if self.exchange:
+            self._all_reduce_mean(self._flat_a)
+        out = self.stage_finish()
         self.updates += 1
-        return {"critic_loss": critic_loss.detach(), "actor_loss": actor_loss.detach(),
-                "alpha": self.log_alpha.exp().detach(), "entropy": -logp.detach().mean()}
+        return out
 
     def state_dict(self):
         return {"actor": self.actor.state_dict(), "critic": self.critic.state_dict(),
@@ -359,8 +418,8 @@ def train_sac(env, agent: SAC, total_vector_steps: int, buffer: Optional[DeviceR
 
 def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional[DeviceReplayBuffer] = None,
                       reward_fn=None, stop_at_first_food: bool = False, poll_every: int = 8,
-                      warmup_iters: int = 3) -> Dict[str, float]:
-    """`train_sac` with one hipGraph replay per vector step.
+                      warmup_iters: int = 3, force_segments: bool = False) -> Dict[str, float]:
+    """`train_sac` with hipGraph replays instead of ~250 kernel launches per vector step.
 
     One training iteration is ~250 small kernels (policy forward, `salp_vec_step`, replay insert, twin-critic
     / actor / entropy updates, polyak): issued one by one the host is the bottleneck (~5 ms per iteration at
@@ -368,12 +427,19 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
     C ABI, the buffer insert with a device-side cursor, sampling, the three optimiser steps — is captured
     once per phase (random actions before `learning_starts`, policy + updates after) and replayed; the host
     only polls a device flag every `poll_every` steps.  Same algorithm and hyper-parameters as `train_sac`;
-    `reward_fn`, if given, must be capturable (pure device ops, no host reads)."""
+    `reward_fn`, if given, must be capturable (pure device ops, no host reads).
+
+    Data-parallel replicas (`SAC(data_parallel=True)`, one process per GPU): a collective cannot sit inside the
+    captured region here, so the iteration is captured as SEGMENTS that end where gradients must be exchanged
+    (`SAC.stage_critic / stage_actor / stage_finish`): [act + env step + insert + sample + critic backward]
+    all-reduce [critic step + actor backward] all-reduce [actor step + polyak (+ next update's critic backward)]…
+    — 1 + 2 x updates_per_step replays and 2 x updates_per_step small all-reduces per vector step, every rank
+    replaying the same sequence.  `force_segments=True` uses the segmented form at world size 1 (tests)."""
     cfg, dev = agent.cfg, agent.device
     if dev.type != "cuda":
         raise RuntimeError("train_sac_graphed needs a ROCm device")
-    if agent.world > 1:
-        raise RuntimeError("train_sac_graphed is single-process; use train_sac for data-parallel replicas")
+    segmented = agent.world > 1 or force_segments
+    agent.exchange = segmented
     n = env.num_envs
     buffer = buffer or DeviceReplayBuffer(cfg.buffer_size, env.obs_dim, env.act_dim, dev)
     low = torch.as_tensor(env.single_action_space.low, device=dev)
@@ -387,7 +453,7 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
     first_t = torch.full((), -1, device=dev, dtype=torch.long)
     last: Dict[str, torch.Tensor] = {}
 
-    def iteration(random_actions: bool, learn: bool):
+    def seg_act(random_actions: bool, learn: bool):
         with torch.no_grad():
             if random_actions:
                 act = low + (high - low) * torch.rand((n, env.act_dim), device=dev)
@@ -407,15 +473,59 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
             first_t.copy_(torch.where((first_t < 0) & hit, step_t, first_t))
             obs.copy_(nobs)
         if learn:
-            for _ in range(cfg.updates_per_step):
-                out = agent.update(buffer.sample_capturable(cfg.batch_size))
-            for k, v in out.items():
-                if k in last:
-                    last[k].copy_(v)
-                else:
-                    last[k] = v.clone()
+            agent.stage_critic(buffer.sample_capturable(cfg.batch_size))
 
-    graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
+    def seg_finish(more: bool):
+        out = agent.stage_finish()
+        for k, v in out.items():
+            if k in last:
+                last[k].copy_(v)
+            else:
+                last[k] = v.clone()
+        if more:
+            agent.stage_critic(buffer.sample_capturable(cfg.batch_size))
+
+    def plan(random_actions: bool, learn: bool):
+        """The iteration as a list of ("run", fn) / ("reduce", flat-name) items; a new graph segment starts after
+        every reduce.  Unsegmented: the same functions with nothing between them (one graph)."""
+        items = [("run", lambda: seg_act(random_actions, learn))]
+        if learn:
+            ups = cfg.updates_per_step
+            for u in range(ups):
+                items += [("reduce", "_flat_c"), ("run", agent.stage_actor), ("reduce", "_flat_a"),
+                          ("run", (lambda more: (lambda: seg_finish(more)))(u + 1 < ups))]
+        if not segmented:
+            items = [it for it in items if it[0] == "run"]
+        return items
+
+    def run_eager(items):
+        for kind, x in items:
+            if kind == "run":
+                x()
+            else:
+                agent._all_reduce_mean(getattr(agent, x))
+
+    def capture(items):
+        """[(graph | None, reduce-name | None)]: consecutive "run" items share one graph segment."""
+        segs, cur = [], []
+        for kind, x in items + [("reduce", None)]:
+            if kind == "run":
+                cur.append(x)
+                continue
+            if cur:
+                g = torch.cuda.CUDAGraph()
+                fns = list(cur)
+                with torch.cuda.graph(g, pool=pool):
+                    for f in fns:
+                        f()
+                segs.append((g, x))
+                cur = []
+            elif x is not None:
+                segs.append((None, x))
+        return segs
+
+    pool = torch.cuda.graph_pool_handle()
+    graphs: Dict[tuple, list] = {}
     warm: Dict[tuple, int] = {}
     side = torch.cuda.Stream(device=dev)
     t0 = time.perf_counter()
@@ -430,7 +540,11 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
             if learn and t_learn is None:
                 torch.cuda.synchronize(dev)
                 t_learn, learn_from = time.perf_counter(), step
-            graphs[key].replay()
+            for g, red in graphs[key]:
+                if g is not None:
+                    g.replay()
+                if red is not None:
+                    agent._all_reduce_mean(getattr(agent, red))
             if learn:
                 agent.updates += cfg.updates_per_step
         elif warm.get(key, 0) < warmup_iters:
@@ -438,22 +552,26 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
             # optimiser state must exist before capture
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                iteration(random_actions, learn)
+                run_eager(plan(random_actions, learn))
             torch.cuda.current_stream(dev).wait_stream(side)
+            if learn:
+                agent.updates += cfg.updates_per_step
             warm[key] = warm.get(key, 0) + 1
         else:
-            g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize(dev)
-            upd = agent.updates
-            with torch.cuda.graph(g):
-                iteration(random_actions, learn)
-            agent.updates = upd            # capture runs no kernel
-            graphs[key] = g
+            graphs[key] = capture(plan(random_actions, learn))      # capture runs no kernel
             continue
         step += 1
         buffer.advance_host(n)
         if first_food_s is None and (step % poll_every == 0 or step == total_vector_steps):
-            f = int(first_t.item())                      # the only host read of the loop
+            if agent.world > 1:      # every rank must leave the loop at the same step: earliest capture of any replica
+                import torch.distributed as dist
+                f_t = torch.where(first_t < 0, torch.full_like(first_t, 1 << 60), first_t)
+                dist.all_reduce(f_t, op=dist.ReduceOp.MIN, group=agent.pg)
+                f = int(f_t.item())
+                f = -1 if f >= (1 << 60) else f
+            else:
+                f = int(first_t.item())                  # the only host read of the loop
             if f >= 0:
                 first_food_s, first_food_step = time.perf_counter() - t0, f
                 if stop_at_first_food:
@@ -464,7 +582,8 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
     return {"wall_s": wall, "vector_steps": step, "env_steps": step * n, "updates": agent.updates,
             "first_food_wall_s": first_food_s, "first_food_vector_step": first_food_step,
             "episodes": finished, "mean_return": float(fin_ret.item()) / max(finished, 1),
-            "graphs": len(graphs),
+            "graphs": sum(1 for segs in graphs.values() for g, _ in segs if g is not None),
+            "segmented": segmented,
             "learn_ms_per_vector_step": None if t_learn is None or step <= learn_from else
             (t0 + wall - t_learn) * 1e3 / (step - learn_from),
             **{k: float(v) for k, v in last.items()}}
