@@ -82,12 +82,27 @@ def cpu_baseline(cfg, budget_s: float):
         orc1.rollout(a1)
         r1 += 1
     rate1 = r1 * 2048 * H / (time.perf_counter() - t1)
-    return {
+    out = {
         "value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": f"C oracle (fp64, libm), OpenMP over envs: {n} envs x {H}-step rollouts x {reps} reps "
                   f"({el:.1f} s), same env parameters, all outputs written",
         "one_core_value": rate1,
     }
+    # The reference's own pure-Python step cannot be timed here (its files do not travel to the GPU box): its rate
+    # is the one measured in the build container by tests/golden/time_reference.py (BASELINE configs[0]).
+    rp = os.path.join(ROOT, "profiles", "reference_cpu_rate.json")
+    if os.path.isfile(rp):
+        try:
+            with open(rp) as f:
+                rj = json.load(f)
+            out["python_reference"] = {
+                "value": rj["env_steps_per_s_median"], "unit": "env-steps/s", "cores": rj.get("cores", 1),
+                "label": "measured in the build container, not on this host", "workload": rj.get("what"),
+                "cpu": rj.get("cpu"), "python": rj.get("python"), "numpy": rj.get("numpy"), "script": rj.get("script"),
+            }
+        except Exception:   # noqa: BLE001
+            pass
+    return out
 
 
 def sac_first_capture(device, world: int, rank: int, envs: int = 4096, max_steps: int = 600):
