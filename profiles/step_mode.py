@@ -27,5 +27,6 @@ def run(n, preset="single_food_long_horizon", iters=300):
     return out
 
 if __name__ == "__main__":
-    for n in (4096, 65536, 262144, 1048576):
-        print(json.dumps(run(n)))
+    sizes = [int(a) for a in sys.argv[1:]] or [4096, 65536, 262144, 1048576]
+    for n in sizes:
+        print(json.dumps(run(n)), flush=True)

@@ -43,3 +43,23 @@ def test_pursuit_policy_reaches_the_goal_and_matches_the_oracle():
     assert np.isfinite(m["path_ratio"]).all() and (m["path_ratio"][m["success"]] >= 0.89).all()
     assert (m["steps"] <= 3000).all() and (m["steps"][m["success"]] < 3000).all()
     print("pursuit baseline:", {k: round(v, 3) if isinstance(v, float) else v for k, v in s.items()})
+
+
+def test_metrics_match_the_reference_run_single_trial_on_scripted_paths():
+    """tests/golden/nav_metrics.npz (gen_nav_golden.py): the reference's own `NavigationDataCollector.run_single_trial`
+    (eval/collect_navigation_data.py:73-196) on six scripted paths — a goal-reaching sine, a path with stalls, a 3-point
+    path (no spline), one that never arrives, a double loop, a short random walk.  Every metric incl. the
+    spline-smoothed path ratio (:138-165) to 1e-9 relative."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nav_metrics.npz"))
+    steps = z["steps"].astype(np.int64)
+    m = navigation_metrics(z["pos"], steps, z["start"], z["goal"], float(z["goal_radius"]))
+    for k in ("path_length", "path_ratio", "straightness", "final_distance", "lateral_deviation", "area_covered",
+              "area_ratio", "x_range", "y_range", "spline_path_length", "spline_path_ratio"):
+        ref, got = z[k], m[k]
+        assert np.array_equal(np.isnan(ref), np.isnan(got)), k
+        ok = ~np.isnan(ref)
+        assert np.allclose(got[ok], ref[ok], rtol=1e-9, atol=1e-9), (k, got, ref)
+    assert np.array_equal(m["success"], z["success"].astype(bool))
+    assert np.isnan(m["spline_path_ratio"][2]) and np.isfinite(m["spline_path_ratio"][[0, 1, 3, 4, 5]]).all()
+    assert summarize(m)["avg_spline_path_ratio"] == pytest.approx(float(np.nanmean(z["spline_path_ratio"])), rel=1e-9)

@@ -96,6 +96,34 @@ def run_navigation_trials(policy: Callable, num_trials: int = 100, start_pos=(15
     return out
 
 
+def spline_path_length(positions: np.ndarray, goal: np.ndarray) -> float:
+    """The smoothed path length of eval/collect_navigation_data.py:138-165 for ONE trial (`positions` [L, 2], the
+    recorded positions start..stop): consecutive duplicates removed, ~20 control points (every len // 20-th point,
+    the last one always kept), a cubic smoothing spline through them (`splprep(s=500, k=3)`), its length over 500
+    samples plus the distance from its last sample to the goal.  NaN when fewer than 4 points are left (the
+    reference reports None) or scipy is missing."""
+    try:
+        from scipy.interpolate import splev, splprep
+    except ImportError:
+        return float("nan")
+    keep = np.ones(len(positions), bool)
+    keep[1:] = np.any(positions[1:] != positions[:-1], axis=1)
+    uniq = positions[keep]
+    if len(uniq) < 4:
+        return float("nan")
+    ctrl = uniq[::max(1, len(uniq) // 20)]
+    if not np.array_equal(ctrl[-1], uniq[-1]):
+        ctrl = np.vstack([ctrl, uniq[-1]])
+    if len(ctrl) < 4:
+        return float("nan")
+    try:
+        tck, _ = splprep([ctrl[:, 0], ctrl[:, 1]], s=500.0, k=3)
+        sp = np.column_stack(splev(np.linspace(0, 1, 500), tck))
+    except Exception:   # noqa: BLE001 — the reference swallows fit failures too (:164)
+        return float("nan")
+    return float(np.linalg.norm(np.diff(sp, axis=0), axis=1).sum() + np.linalg.norm(sp[-1] - goal))
+
+
 def navigation_metrics(pos: np.ndarray, steps: np.ndarray, start: np.ndarray, goal: np.ndarray,
                        goal_radius: float = 50.0) -> Dict[str, np.ndarray]:
     """pos: [T+1, N, 2] with the position frozen after a trial stopped; steps: [N] steps taken."""
@@ -113,12 +141,14 @@ def navigation_metrics(pos: np.ndarray, steps: np.ndarray, start: np.ndarray, go
     xmin, xmax = pos[..., 0].min(axis=0), pos[..., 0].max(axis=0)
     ymin, ymax = pos[..., 1].min(axis=0), pos[..., 1].max(axis=0)
     area = (xmax - xmin) * (ymax - ymin)
+    spline_len = np.array([spline_path_length(pos[: steps[i] + 1, i], goal) for i in range(n)])
     return {
         "steps": steps.astype(np.int64), "path_length": path_length, "final_distance": final_distance,
         "success": final_distance < goal_radius, "path_ratio": path_length / optimal,
         "straightness": optimal / np.maximum(path_length, 1e-12), "lateral_deviation": lat_mean,
         "area_covered": area, "area_ratio": area / (optimal * goal_radius * 2), "x_range": xmax - xmin,
         "y_range": ymax - ymin, "optimal_distance": np.full(n, optimal),
+        "spline_path_length": spline_len, "spline_path_ratio": spline_len / optimal,
     }
 
 
@@ -128,7 +158,9 @@ def summarize(m: Dict[str, np.ndarray]) -> Dict[str, float]:
     return {
         "num_trials": int(len(ok)), "success_rate": float(ok.mean()), "successful_trials": int(ok.sum()),
         "avg_path_length": float(m["path_length"].mean()), "std_path_length": float(m["path_length"].std()),
-        "avg_path_ratio": float(m["path_ratio"].mean()), "avg_straightness": float(m["straightness"].mean()),
+        "avg_path_ratio": float(m["path_ratio"].mean()),
+        "avg_spline_path_ratio": float(np.nanmean(m["spline_path_ratio"])) if np.isfinite(m["spline_path_ratio"]).any() else None,
+        "avg_straightness": float(m["straightness"].mean()),
         "std_straightness": float(m["straightness"].std()), "avg_steps": float(m["steps"].mean()),
         "std_steps": float(m["steps"].std()), "avg_lateral_deviation": float(m["lateral_deviation"].mean()),
         "avg_final_distance": float(m["final_distance"].mean()), "avg_area_covered": float(m["area_covered"].mean()),
