@@ -18,6 +18,12 @@ class AdaptiveFoodCurriculum:
     def __init__(self, env, min_food_count: int = 2, max_food_count: int = 12, window: int = 10,
                  harder_above: float = 0.6, easier_below: float = 0.25):
         self.env = env
+        slots = int(getattr(getattr(env, "cfg", None), "num_food_items", max_food_count))
+        if int(max_food_count) > slots:
+            # the reference's write simply grows the food list; the batched state has a fixed number of food slots
+            raise ValueError(f"the env was created with num_food_items={slots} food slots, the curriculum may ask for up "
+                             f"to {max_food_count}: create the env with num_food_items >= max_food_count "
+                             f"(and start lower with `env.base_num_food_items = k`)")
         self.min_food_count, self.max_food_count = int(min_food_count), int(max_food_count)
         self.window, self.harder_above, self.easier_below = int(window), float(harder_above), float(easier_below)
         self.current_food_count = int(env.base_num_food_items)

@@ -16,7 +16,9 @@ envs flagged in `info["_final_observation"]`.  Attribute pokes of the reference'
 
 `SalpSB3VecEnv` adapts it to stable-baselines3's `VecEnv` duck type (`step_async/step_wait`,
 `dones = terminated | truncated`, `infos[i]["terminal_observation"]`,
-`infos[i]["TimeLimit.truncated"]`), so `SAC("MlpPolicy", env, ...)` (train.py:60-70) can take it.
+`infos[i]["TimeLimit.truncated"]`); `SalpSB3VecEnv.as_sb3_vecenv(...)` makes it a true `VecEnv` subclass where
+stable-baselines3 is installed, which is what `SAC("MlpPolicy", env, ...)` (train.py:60-70) checks for
+(parity unpinned: SB3 is not importable in the build environment).
 
 PyTorch is used for device buffers and streams only; every simulation call goes through the
 C ABI.  If the HIP library or a GPU is missing the constructor raises — there is no CPU path.
@@ -111,7 +113,7 @@ class SalpVectorEnv:
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask=None):
         """Resets every env (or those in `mask`).  `seed` re-keys the draw streams (the reference's
         reset(seed) only seeds gymnasium's unused np_random, snake:136)."""
-        if seed is not None and int(seed) != self.seed_value:
+        if seed is not None:      # any explicit seed restarts the draw streams: reset(seed=s) twice gives the same episodes
             base_food = self._lib.base_num_food
             self._lib.close()
             self.seed_value = int(seed)
@@ -365,7 +367,24 @@ class _LazyInfos(Sequence):
 
 
 class SalpSB3VecEnv:
-    """stable-baselines3 `VecEnv` duck type over SalpVectorEnv (numpy in / numpy out)."""
+    """The method surface of stable-baselines3's `VecEnv` over SalpVectorEnv (numpy in / numpy out): `reset`,
+    `step_async` / `step_wait`, `dones = terminated | truncated`, `infos[i]["terminal_observation"]`,
+    `"TimeLimit.truncated"`, `get_attr / set_attr / env_method / env_is_wrapped`.  It is a duck type, NOT a subclass:
+    stable-baselines3 is not installable in the build environment, so whether `SAC("MlpPolicy", env)` accepts it as
+    is — SB3's `_wrap_env` tests `isinstance(env, VecEnv)` — is parity unpinned; `as_sb3_vecenv()` returns an
+    instance of a real `VecEnv` subclass when stable-baselines3 is importable."""
+
+    @classmethod
+    def as_sb3_vecenv(cls, *args, **kwargs):
+        """With stable-baselines3 importable: an instance of a class deriving from BOTH this adapter and SB3's
+        `VecEnv` (so `isinstance(env, VecEnv)` holds and SB3 does not wrap it in a DummyVecEnv); raises
+        ImportError otherwise."""
+        from stable_baselines3.common.vec_env import VecEnv      # ImportError where SB3 is absent
+        sub = type("SalpSB3VecEnvSubclass", (cls, VecEnv), {})
+        self = sub.__new__(sub)
+        cls.__init__(self, *args, **kwargs)
+        VecEnv.__init__(self, self.num_envs, self.observation_space, self.action_space)
+        return self
 
     def __init__(self, config: ConfigLike = "single_food", num_envs: int = 8, device: Union[str, int] = 0,
                  seed: int = 0, **overrides):
