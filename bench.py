@@ -211,6 +211,8 @@ def main():
 
     cfg = pkg.load_env_config(args.preset)
     plan = shard_plan(world, args.envs, args.total_envs, args.weak)
+    if args.preset != "single_food_long_horizon" or args.chunk != 250:
+        plan["config"] = None        # BASELINE configs[2] / [3] are quoted on this preset in 250-step launches: anything else is an override
     n, H, K, W = plan["envs_per_gpu"], args.chunk, args.steps, args.warmup
     gather = args.gather or "all"
 

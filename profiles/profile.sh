@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BARGS="--no-cpu-baseline $@"
+BARGS="--no-cpu-baseline --no-sac-probe $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 10 --warmup 2 $BARGS > $OUT/bench_kt.json 2> $OUT/kt.err
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 4 --warmup 1 $BARGS > /dev/null 2> $OUT/$name.err; }
 pass pmc_fetch FETCH_SIZE
@@ -17,5 +17,5 @@ pass pmc_sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES 
 pass pmc_sq2 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_LDS
 pass pmc_sq3 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_SMEM
 pass pmc_grbm GRBM_GUI_ACTIVE
-python3 bench.py $@ > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+python3 bench.py --no-sac-probe $@ > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 cat $OUT/bench_plain.json

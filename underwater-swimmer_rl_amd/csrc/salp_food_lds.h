@@ -180,7 +180,8 @@ __device__ __forceinline__ StepOut step_env_lds(EnvCore& e, const FoodLds& f, co
 }
 
 // The observation row from a scan of the CURRENT food set around the CURRENT pose.
-template <int KMAX, bool STD>
+// ALLFOUND: every lane shows K live foods (wave-uniform fact established by the caller): no padding selects.
+template <int KMAX, bool STD, bool ALLFOUND = false>
 __device__ __forceinline__ void observe_lds(const EnvCore& e, const DevParams& P, double rmax, int K, const FoodScan<KMAX>& q,
                                             int nlive, bool have_rel, float rel0, float (&o)[12 + 4 * KMAX]) {
   o[0] = (float)e.x * (float)CV(inv_W);
@@ -198,7 +199,7 @@ __device__ __forceinline__ void observe_lds(const EnvCore& e, const DevParams& P
   for (int s = 0; s < KMAX; ++s) {
     float v0 = 0.f, v1 = 0.f, v2 = 1.f, v3 = 0.f;   // padding for an empty slot (snake:412)
     if (s < K) {
-      const bool found = q.idx[s] >= 0;
+      const bool found = ALLFOUND ? true : (q.idx[s] >= 0);
       float rel;
       if (s == 0 && __all(have_rel)) rel = rel0;    // wave-uniform: skips the second atan2
       else {
@@ -214,7 +215,7 @@ __device__ __forceinline__ void observe_lds(const EnvCore& e, const DevParams& P
   }
   const float fcnt = (float)nlive;
   const float s0 = fminf(fcnt * 0.1f, 1.0f);
-  const float s1 = (nlive > 0) ? (q.dsum * __builtin_amdgcn_rcpf(fcnt)) * CV(inv_diag) : 1.0f;
+  const float s1 = (ALLFOUND || nlive > 0) ? (q.dsum * __builtin_amdgcn_rcpf(fcnt)) * CV(inv_diag) : 1.0f;
   if (KMAX == 3) {
     o[22] = s0; o[23] = s1;
   } else {

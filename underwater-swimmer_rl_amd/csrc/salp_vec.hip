@@ -36,6 +36,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #endif
 constexpr int kBlock = SALP_BLOCK;
 constexpr int kWave = 64;
+#ifndef SALP_ALLFOUND_OBS
+#define SALP_ALLFOUND_OBS 1
+#endif
 #ifdef SALP_EXP_HOIST
 #define SALP_MULTI_WAVES 2
 #else
@@ -348,7 +351,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
 
     if (FULL || io.obs) {
       float ob[12 + 4 * KMAX];
-      if constexpr (MULTI) observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
+      if constexpr (REGF) {
+        // all FMAX slots of every lane alive (the steady state with respawn) => every lane shows K foods
+        if (SALP_ALLFOUND_OBS && (KMAX <= FMAX) && K >= 1 && __all(nlive == FMAX)) observe_lds<KMAX, STD, true>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
+        else observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
+      } else if constexpr (LDSF) observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
       else observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
 #ifdef SALP_EXP_DIRECT_STORE   // experiment: per-lane 96-B rows straight from registers (no LDS transpose)
       if (active) {
