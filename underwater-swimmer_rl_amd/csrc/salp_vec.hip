@@ -41,6 +41,8 @@ constexpr int kWave = 64;
 #endif
 #ifdef SALP_EXP_HOIST
 #define SALP_MULTI_WAVES 2
+#elif defined(SALP_EXP_WAVES4)
+#define SALP_MULTI_WAVES 4
 #else
 #define SALP_MULTI_WAVES 3     // multi-food kernels (<= 12 slots): <= 168 VGPRs, 3 wavefronts per SIMD
 #endif
@@ -117,7 +119,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
 #endif
   constexpr bool MULTI = REGF || LDSF;
   __shared__ __attribute__((aligned(16))) double2 food_lds[LDSF ? (kBlock / kWave) * FMAX * kWave : 1];
-  __shared__ __attribute__((aligned(16))) float2 off_lds[REGF ? (kBlock / kWave) * FMAX * kWave : 1];
+  // The fp32 offsets of the register-food pass live for the middle of a step (pass -> selection), the observation
+  // tile for its end (row writes -> flush): with 12 slots both are 6144 B per wavefront and share the same bytes
+  // (LDS operations of a wavefront execute in order; a wavefront fence separates the two uses for the compiler).
+  constexpr bool ALIAS_OFFS = REGF && (2 * FMAX <= PITCH);
+  __shared__ __attribute__((aligned(16))) float2 off_lds[(REGF && !ALIAS_OFFS) ? (kBlock / kWave) * FMAX * kWave : 1];
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
   using EnvT = std::conditional_t<LDSF, EnvCore, Env<FMAX>>;
   EnvT e;
   const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
-  const OffsetLds offs{off_lds + (REGF ? (wave * FMAX * kWave + lane) : 0)};
+  const OffsetLds offs{ALIAS_OFFS ? (reinterpret_cast<float2*>(tile) + lane) : (off_lds + (REGF ? (wave * FMAX * kWave + lane) : 0))};
   FoodScan<KMAX> fq;          // MULTI: nearest-K selection of the current food set around the current pose
   int nlive = 0;              // MULTI: live foods of this env, recounted whenever the food set changes
   if constexpr (LDSF) {
@@ -366,6 +372,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
       }
       if (rows < 0)
 #endif
+      if constexpr (ALIAS_OFFS) {   // the selection's offset reads come before the row writes to the same bytes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
 #pragma unroll
       for (int q = 0; q < QMAX; ++q)   // 16-B LDS stores, conflict-free (see the tile layout above)
         if (q < Q) ((q & 1) ? myrow_odd : myrow_even)[q] = make_float4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
