@@ -430,22 +430,29 @@ __device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint
 // The reference evaluates cos/sin at three angles: phi, fl(phi + pi/2) and fl(phi + jitter).  One
 // sincos(phi) serves all three: the side angle is a quarter turn plus the (exactly recovered)
 // rounding error of the addition, the jitter angle a rotation by |D| <= 0.025 (short series).
-template <int FMAX, bool STD>
-__device__ __forceinline__ void apply_jet_thrust(EnvCore& e, const DevParams& P, uint64_t genv, double r) {
+// The seven increments of one thrust step, in the order legacy:261-314 applies them:
+//   vx = ((vx + t.ax) + t.bx) + t.cx,  vy likewise,  omega = omega + t.om
+// (main jet, side thrust, jitter).  A function of (theta, nozzle, water before this step's decay, r = max(a, b),
+// the env's draw counter and global index) only — so it can be evaluated by ANY lane (ThrustPool below).
+struct ThrustTerms { double ax, ay, bx, by, cx, cy, om; };
+template <bool STD>
+__device__ __forceinline__ ThrustTerms jet_thrust_terms(double th, double noz, double water, double r, uint32_t rng,
+                                                        uint64_t genv, const DevParams& P) {
+  ThrustTerms t;
   tbl_double* TT = thrust_table();
-  const double T = mul_s(CV(thrust_force) * e.water, TT[TT_K04]);
-  const double phi = e.th - e.noz;
+  const double T = mul_s(CV(thrust_force) * water, TT[TT_K04]);
+  const double phi = th - noz;
   double s, c;
   sincos_small_t(TT, phi, s, c);
-  e.vx = e.vx + mul_s(c * T, TT[TT_K012]);
-  e.vy = e.vy + mul_s(s * T, TT[TT_K012]);
-  const double nn = -e.noz;
+  t.ax = mul_s(c * T, TT[TT_K012]);
+  t.ay = mul_s(s * T, TT[TT_K012]);
+  const double nn = -noz;
   const double primary = mul_s(nn * T, TT[TT_K0002]);
   const double arm = r * TT[TT_K07];
   const double perp = T * sin_nozzle_t(TT, nn);
   const double moment = mul_s(perp * arm, TT[TT_K00005]);
-  const double shape = mul_s((nn * T) * e.water, TT[TT_K00003]);
-  e.om = e.om + ((primary + moment) + shape);
+  const double shape = mul_s((nn * T) * water, TT[TT_K00003]);
+  t.om = (primary + moment) + shape;
   {  // side thrust at fl(phi + fl(pi/2)) = phi + pi/2 + dl,  dl = (fl(pi/2) - pi/2) - err
     const double pio2 = TT[TT_PIO2];
     const double side = phi + pio2;
@@ -454,12 +461,14 @@ __device__ __forceinline__ void apply_jet_thrust(EnvCore& e, const DevParams& P,
     const double dl = TT[TT_DL] - err;
     const double sc = -fma(dl, c, s);     // cos(side) = -sin(phi + dl)
     const double ss = fma(-dl, s, c);     // sin(side) =  cos(phi + dl)
-    const double S = mul_s(T * fabs(e.noz), TT[TT_K03]);
-    e.vx = e.vx + mul_s(sc * S, TT[TT_K008]);
-    e.vy = e.vy + mul_s(ss * S, TT[TT_K008]);
+    const double S = mul_s(T * fabs(noz), TT[TT_K03]);
+    t.bx = mul_s(sc * S, TT[TT_K008]);
+    t.by = mul_s(ss * S, TT[TT_K008]);
   }
-  {  // jitter at fl(phi + d), d = fl((u - 0.5) * 0.05)
-    const U4 w = next_block(e, P, genv);
+  {  // jitter at fl(phi + d), d = fl((u - 0.5) * 0.05); one Philox block of the env's draw stream (counter rng)
+    uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
+    asm volatile("" : "+s"(k0), "+s"(k1));    // see next_block
+    const U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), rng, 0u, k0, k1);
     const double u = u53(w.x, w.y);
     const double d = mul_s(u - 0.5, TT[TT_K005]);
     const double na = phi + d;
@@ -478,8 +487,84 @@ __device__ __forceinline__ void apply_jet_thrust(EnvCore& e, const DevParams& P,
     const double nc = c * cD - s * sD;
     const double ns = s * cD + c * sD;
     const double nf = T * TT[TT_K004];
-    e.vx = e.vx + mul_s(nc * nf, TT[TT_K0002J]);
-    e.vy = e.vy + mul_s(ns * nf, TT[TT_K0002J]);
+    t.cx = mul_s(nc * nf, TT[TT_K0002J]);
+    t.cy = mul_s(ns * nf, TT[TT_K0002J]);
+  }
+  return t;
+}
+__device__ __forceinline__ void apply_thrust_terms(EnvCore& e, const ThrustTerms& t) {
+  e.vx = ((e.vx + t.ax) + t.bx) + t.cx;
+  e.vy = ((e.vy + t.ay) + t.by) + t.cy;
+  e.om = e.om + t.om;
+  e.rng += 1u;
+}
+// legacy:261-314 _apply_jet_thrust (water is the value BEFORE this step's decay), the lane serving itself.
+template <int FMAX, bool STD>
+__device__ __forceinline__ void apply_jet_thrust(EnvCore& e, const DevParams& P, uint64_t genv, double r) {
+  apply_thrust_terms(e, jet_thrust_terms<STD>(e.th, e.noz, e.water, r, e.rng, genv, P));
+}
+
+// ---- block-pooled thrust (experiment, -DSALP_EXP_POOL; measured slower, see salp_vec.hip) ---------------
+// The thrust block is ~200 VALU instructions and runs for a wavefront whenever ANY of its 64 lanes thrusts; the
+// breathing phases of the lanes are desynchronised by autoresets, so that is nearly every step, with ~22 % of the
+// lanes active (the exhale window is 61 of 273 steps).  The four wavefronts of a workgroup hold ~56 thrusting
+// lanes per step between them — one wavefront's worth.  With POOL the thrusting lanes of the whole workgroup
+// push their inputs into an LDS queue, ONE wavefront (rotating with the step number; a second one if more than 64
+// entries) evaluates jet_thrust_terms for all of them at full lane occupancy, and the owners read their seven
+// increments back and apply them in the reference's order: bit-identical results, a quarter of the thrust
+// instructions.  Cost: two workgroup barriers per step — every wavefront of the workgroup executes exactly two,
+// unconditionally, in every step of the loop (the host launches the pooled kernel on whole 256-env workgroups
+// only), so the barriers cannot deadlock.
+// Inputs and outputs are separate LDS regions, each single-buffered, and that is race-free: inputs are written
+// before barrier 1 of a step and read between its barriers 1 and 2 — a wavefront that writes the NEXT step's
+// inputs has passed barrier 2, i.e. the readers are done; outputs are written between the barriers and read by
+// their owners after barrier 2 — they are rewritten after barrier 1 of the next step, which every owner only
+// reaches after its reads.  (Outputs aliased onto the inputs would not be: a fast wavefront's next inputs could
+// overwrite outputs a slow owner has not read yet.)
+struct ThrustPool {
+  double* in;           // [4][256]: th, noz, water, r
+  double* out;          // [7][256]: the seven increments
+  uint2* meta;          // [256]: (draw counter, owner = wave * 64 + lane)
+  unsigned* count;      // [2]: entries of the current step (double-buffered by step parity)
+  uint64_t genv_block0; // global env index of the workgroup's first env
+  int wave, lane, t;
+};
+constexpr int kPoolN = 256;
+
+template <bool STD>
+__device__ __forceinline__ void pooled_thrust(EnvCore& e, const DevParams& P, const ThrustPool& q, bool thrust, double r) {
+  const int buf = q.t & 1;
+  const unsigned long long m = __ballot(thrust);
+  const unsigned cnt = (unsigned)__popcll(m);
+  unsigned base = 0;
+  if (q.lane == 0) base = atomicAdd(&q.count[buf], cnt);
+  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+  const unsigned slot = base + (unsigned)__popcll(m & ((1ull << q.lane) - 1ull));
+  if (thrust) {
+    q.in[0 * kPoolN + slot] = e.th; q.in[1 * kPoolN + slot] = e.noz; q.in[2 * kPoolN + slot] = e.water; q.in[3 * kPoolN + slot] = r;
+    q.meta[slot] = make_uint2(e.rng, (unsigned)(q.wave * 64 + q.lane));
+  }
+  __syncthreads();                                   // barrier 1: every entry of the step is queued
+  const unsigned M = q.count[buf];
+  for (unsigned g = 0; g * 64u < M; ++g) {           // wave-uniform
+    if (((unsigned)q.t + g) % 4u == (unsigned)q.wave) {
+      const unsigned i = g * 64u + (unsigned)q.lane;
+      if (i < M) {
+        const uint2 mt = q.meta[i];
+        const ThrustTerms tt = jet_thrust_terms<STD>(q.in[0 * kPoolN + i], q.in[1 * kPoolN + i], q.in[2 * kPoolN + i],
+                                                     q.in[3 * kPoolN + i], mt.x, q.genv_block0 + (uint64_t)mt.y, P);
+        q.out[0 * kPoolN + i] = tt.ax; q.out[1 * kPoolN + i] = tt.ay; q.out[2 * kPoolN + i] = tt.bx; q.out[3 * kPoolN + i] = tt.by;
+        q.out[4 * kPoolN + i] = tt.cx; q.out[5 * kPoolN + i] = tt.cy; q.out[6 * kPoolN + i] = tt.om;
+      }
+    }
+  }
+  __syncthreads();                                   // barrier 2: every entry is answered
+  if (q.wave == 0 && q.lane == 0) q.count[buf] = 0u; // this buffer is pushed to again two steps from now
+  if (thrust) {
+    ThrustTerms tt;
+    tt.ax = q.out[0 * kPoolN + slot]; tt.ay = q.out[1 * kPoolN + slot]; tt.bx = q.out[2 * kPoolN + slot]; tt.by = q.out[3 * kPoolN + slot];
+    tt.cx = q.out[4 * kPoolN + slot]; tt.cy = q.out[5 * kPoolN + slot]; tt.om = q.out[6 * kPoolN + slot];
+    apply_thrust_terms(e, tt);
   }
 }
 
@@ -602,8 +687,9 @@ struct StepOut {
 // limit = 50) when o.collected && P.respawn, BEFORE any autoreset so the draw order of the
 // reference is kept.  (The all-collected termination test only applies when !P.respawn.)
 // legacy:119-156 up to and including the wall bounce; returns r = max(ellipse_a, ellipse_b) of this step.
-template <bool FORCED, bool STD, bool HOIST = false>
-__device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint64_t genv, float a0, float a1, const HotK& hk = HotK()) {
+template <bool FORCED, bool STD, bool HOIST = false, bool POOL = false>
+__device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint64_t genv, float a0, float a1, const HotK& hk = HotK(),
+                                            const ThrustPool* pool = nullptr) {
   int phase = bw_phase(e.packed), timer = bw_timer(e.packed), dur = bw_dur(e.packed);
   // legacy:121-135
   double nd;
@@ -691,7 +777,8 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
 #ifdef SALP_EXP_NO_THRUST      // experiment build (profiles/ab_bench.py): price of the thrust block
   thrust = false;
 #endif
-  if (thrust) apply_jet_thrust<1, STD>(e, P, genv, r);
+  if constexpr (POOL) pooled_thrust<STD>(e, P, *pool, thrust, r);     // two workgroup barriers, executed by every lane
+  else if (thrust) apply_jet_thrust<1, STD>(e, P, genv, r);
   e.water = water_next;
   e.packed = pack_breath(phase, timer, dur, hold);
   // legacy:316-352 _update_physics

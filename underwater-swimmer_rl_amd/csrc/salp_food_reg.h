@@ -99,10 +99,10 @@ __device__ __forceinline__ void clear_slot(Env<FMAX>& e, bool doit, int k) {
 }
 
 // One reference step of a multi-food env (the register counterpart of step_env_lds).
-template <int FMAX, int KMAX, bool FORCED, bool STD, bool HOIST>
+template <int FMAX, int KMAX, bool FORCED, bool STD, bool HOIST, bool POOL>
 __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& sc, const DevParams& P, const HotK& hk, uint64_t genv,
-                                                float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive) {
-  const double r = step_head<FORCED, STD, HOIST>(e, P, genv, a0, a1, hk);
+                                                float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, const ThrustPool* pool) {
+  const double r = step_head<FORCED, STD, HOIST, POOL>(e, P, genv, a0, a1, hk, pool);
   StepOut o;
   o.rmax = r;
   const double cr = r + KV(food_radius, CV(food_radius));

@@ -122,6 +122,18 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
   // The fp32 offsets of the register-food pass live for the middle of a step (pass -> selection), the observation
   // tile for its end (row writes -> flush): with 12 slots both are 6144 B per wavefront and share the same bytes
   // (LDS operations of a wavefront execute in order; a wavefront fence separates the two uses for the compiler).
+#ifdef SALP_EXP_POOL   // experiment build: block-pooled thrust (salp_device.h ThrustPool) in whole-workgroup launches of
+  // the register-food kernels.  Bit-identical results, a quarter of the thrust instructions — and 35 % SLOWER
+  // (2.85 against 2.12 ms, profiles/r02/ab_notes.md session 6): the two workgroup barriers per step put the four
+  // wavefronts in lockstep and three of them idle while the fourth evaluates the queue.  Not shipped.
+  constexpr bool POOL = REGF && !RAGGED && kBlock == 256;
+#else
+  constexpr bool POOL = false;
+#endif
+  __shared__ __attribute__((aligned(16))) double pool_in[POOL ? 4 * kPoolN : 1];
+  __shared__ __attribute__((aligned(16))) double pool_out[POOL ? 7 * kPoolN : 1];
+  __shared__ __attribute__((aligned(8))) uint2 pool_meta[POOL ? kPoolN : 1];
+  __shared__ unsigned pool_count[2];
   constexpr bool ALIAS_OFFS = REGF && (2 * FMAX <= PITCH);
   __shared__ __attribute__((aligned(16))) float2 off_lds[(REGF && !ALIAS_OFFS) ? (kBlock / kWave) * FMAX * kWave : 1];
 
@@ -160,6 +172,10 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
   // accumulated with LDS integer atomics inside the rare-event branch instead of living in VGPRs.
   __shared__ unsigned long long blk_stats[16];
   if (tid < 16) blk_stats[tid] = 0ull;
+  if (tid < 2) pool_count[tid] = 0u;
+  if constexpr (POOL) {   // pooled kernels run on whole workgroups only (launch_rollout): a partial one does nothing
+    if (env_begin + ((int64_t)blockIdx.x + 1) * kBlock > env_end) return;   // uniform for the workgroup, before any barrier
+  }
   __syncthreads();
 
   using EnvT = std::conditional_t<LDSF, EnvCore, Env<FMAX>>;
@@ -245,7 +261,10 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
 #else
     StepOut o;
     if constexpr (LDSF) o = step_env_lds<KMAX, FORCED, STD>(e, food, P, genv, c0, c1, K, fq, nlive);
-    else if constexpr (REGF) o = step_env_reg<FMAX, KMAX, FORCED, STD, kHoist>(e, offs, P, hotk, genv, c0, c1, K, fq, nlive);
+    else if constexpr (REGF) {
+      ThrustPool pool{pool_in, pool_out, pool_meta, pool_count, P.env_base + (uint64_t)(env_begin + (int64_t)blockIdx.x * kBlock), wave, lane, t};
+      o = step_env_reg<FMAX, KMAX, FORCED, STD, kHoist, POOL>(e, offs, P, hotk, genv, c0, c1, K, fq, nlive, &pool);
+    }
     else o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
 #endif
     const bool done = o.terminated || o.truncated;
@@ -739,7 +758,15 @@ struct Bump {  // carve sub-buffers out of the staging allocation
 int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
   const bool full = io.obs && io.reward && io.terminated && io.truncated && !io.final_obs && !io.info;
   const bool gen = io.act == nullptr;               // only reached when can_generate_in_kernel()
-  int64_t n_full = h->n / kWave * kWave;            // envs in full wavefronts: unpredicated kernel
+  // envs in full wavefronts: unpredicated kernel; the register-food kernels pool the thrust work of a workgroup
+  // (ThrustPool) and take whole 256-env workgroups
+#ifdef SALP_EXP_POOL
+  const bool pooled = h->kmax == 3 && h->std_consts && h->fmax > 1 && h->fmax <= 12;
+#else
+  const bool pooled = false;
+#endif
+  const int64_t gran = pooled ? kBlock : kWave;
+  int64_t n_full = h->n / gran * gran;
   // A small ragged batch (step-per-launch acting loops) is launch-bound: one predicated launch over the whole
   // range instead of two; the predicates only cost when the write stream is the bound.
   if (n_full < h->n && h->n * (int64_t)H <= (int64_t)1 << 22) n_full = 0;
