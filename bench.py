@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+XGMI_LINK_GBS = 153.0  # per xGMI link (task statement: 7 links x ~153 GB/s per GPU, point-to-point)
 
 
 def algorithmic_bytes_per_env_step(cfg, horizon: int) -> float:
@@ -172,6 +173,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sac-probe", action="store_true", help="skip the configs[4] first-food-capture probe")
+    ap.add_argument("--sac-probe", action="store_true", help="--gpus G > 1: run the configs[4] probe data-parallel on every rank "
+                    "(off by default there: that path — graph segments + RCCL gradient all-reduces — is covered by gloo and "
+                    "world-size-1 tests only, and a scaling run must not depend on it)")
     args = ap.parse_args()
 
     import torch
@@ -349,7 +353,19 @@ def main():
         },
         "episodes_finished": stats["episodes"], "food_collected": stats["food_collected"],
     }
-    if not args.no_sac_probe and not rehearsal and not force_sharded:
+    if senv is not None:
+        # what the launches cost with and without the exchange, and the exchange against the xGMI links it can use
+        block = H * n * cfg.obs_dim * 4
+        recv = {"all": (world - 1) * block, "final": (world - 1) * n * cfg.obs_dim * 4, "none": 0}[gather]
+        line["kernel_side_value"] = float(world) * n * H / avg_kernel_s        # env-steps/s if only the rollout kernels counted
+        line["exchange"] = {
+            "mode": gather, "recv_bytes_per_rank_per_launch": recv, "wall_s_per_launch": elapsed / K,
+            "recv_GBps_per_rank": recv / (elapsed / K) / 1e9 if recv else 0.0,
+            "xgmi_peak_GBps_per_rank": XGMI_LINK_GBS * min(max(world - 1, 0), 7),
+            "note": "the all-gather of every returned observation moves (G-1) x chunk x N/G x obs_dim x 4 B into each rank per "
+                    "launch: the whole-job value is the exchange's rate when that exceeds the kernel time (DESIGN.md §7)",
+        }
+    if not args.no_sac_probe and not rehearsal and not force_sharded and (world == 1 or args.sac_probe):
         probe = sac_first_capture(device, world if senv is not None else 1, rank)   # every rank takes part (collectives)
         line["sac_first_capture"] = probe
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
