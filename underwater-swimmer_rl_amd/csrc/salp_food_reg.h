@@ -101,7 +101,11 @@ __device__ __forceinline__ void clear_slot(Env<FMAX>& e, bool doit, int k) {
 // One reference step of a multi-food env (the register counterpart of step_env_lds).
 template <int FMAX, int KMAX, bool FORCED, bool STD, bool HOIST, bool POOL>
 __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& sc, const DevParams& P, const HotK& hk, uint64_t genv,
-                                                float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, const ThrustPool* pool) {
+                                                float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, const ThrustPool* pool,
+                                                const DevParams* cold) {
+  // `cold`: the device-memory copy of the launch constants (ColdBlock).  The capture bonus and the collision
+  // penalty are read from it inside the wave-uniform branches that need them (a few percent of the steps), so
+  // their four fp64 constants and two predicate masks do not sit in — and get spilled from — scalar registers.
   const double r = step_head<FORCED, STD, HOIST, POOL>(e, P, genv, a0, a1, hk, pool);
   StepOut o;
   o.rmax = r;
@@ -111,10 +115,15 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& s
   bool all_live = (KMAX <= FMAX) && __all(nlive == FMAX);     // wave-uniform; then every lane also has K foods to show
   if (all_live) scan_foods_reg<FMAX, KMAX, false, false, true>(e, sc, P.F, 0.0, q, o.collected, hit_k, cnt_);
   else scan_foods_reg<FMAX, KMAX, false, false>(e, sc, P.F, 0.0, q, o.collected, hit_k, cnt_);
+  double rew = 0.0;                                              // snake:278-327, terms added in the reference's order
   if (__any(q.key[0] < cr2 * KV(cap_slack, 1.00000000001))) {   // see step_env_lds
     scan_foods_reg<FMAX, KMAX, true, true>(e, sc, P.F, cr2, q, o.collected, hit_k, nlive);
     clear_slot<FMAX>(e, o.collected, hit_k);
     all_live = false;
+    const DevParams& C = *cold;
+    double bonus = C.food_reward;
+    if (C.efficiency_bonus > 0) bonus += C.efficiency_bonus * (double)(C.max_steps_wo_food - e.ssf);
+    rew = o.collected ? bonus : 0.0;
   }
   // (a second, select-free copy of the selection for the all-live case costs more registers than it saves
   // instructions: 168 VGPRs + 21 spilled against 145)
@@ -123,12 +132,10 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& s
     const double mg = KV(margin, CV(margin));
     o.collision = (e.x - r <= mg) || (e.x + r >= KV(wall_hi_x, CV(wall_hi_x))) || (e.y - r <= mg) || (e.y + r >= KV(wall_hi_y, CV(wall_hi_y)));
   }
-  double rew = 0.0;
-  if (o.collected) {
-    rew += P.food_reward;
-    if (P.efficiency_bonus > 0) rew += P.efficiency_bonus * (double)(P.max_steps_wo_food - e.ssf);
+  if (__any(o.collision)) {
+    const double pen = cold->collision_penalty;
+    rew = o.collision ? rew + pen : rew;
   }
-  if (o.collision) rew += P.collision_penalty;
   o.rel = relative_heading(q.by[0], q.bx[0], (float)e.th);
   o.rel_valid = q.idx[0] >= 0;
   if (P.prox_w > 0) {

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
     if constexpr (LDSF) o = step_env_lds<KMAX, FORCED, STD>(e, food, P, genv, c0, c1, K, fq, nlive);
     else if constexpr (REGF) {
       ThrustPool pool{pool_in, pool_out, pool_meta, pool_count, P.env_base + (uint64_t)(env_begin + (int64_t)blockIdx.x * kBlock), wave, lane, t};
-      o = step_env_reg<FMAX, KMAX, FORCED, STD, kHoist, POOL>(e, offs, P, hotk, genv, c0, c1, K, fq, nlive, &pool);
+      o = step_env_reg<FMAX, KMAX, FORCED, STD, kHoist, POOL>(e, offs, P, hotk, genv, c0, c1, K, fq, nlive, &pool, &cold->P);
     }
     else o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
 #endif
