@@ -26,6 +26,7 @@
  *     `stream` (a hipStream_t passed as void*, NULL = the null stream).  Without the flag the
  *     pointers are host pointers and the call is synchronous (H2D, kernel, D2H inside).
  *   - a handle is not thread-safe; distinct handles (one per GPU) are independent.
+ *   - every call runs on the handle's device and leaves the caller's current HIP device as it found it.
  *   - there is no CPU fallback: creating a handle without a usable HIP device fails with
  *     SALP_ERR_NO_DEVICE.
  *

@@ -501,6 +501,20 @@ int rfail(int code, const std::string& m) { g_rerr = m; return code; }
     if (_e != hipSuccess) return rfail(_e == hipErrorOutOfMemory ? -4 : -3, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
+// Makes `device` current for the scope of one ABI call and restores the caller's device afterwards, so that the
+// library never changes the current HIP device under the caller (PyTorch keeps its own notion of it).  When the
+// caller is already on the handle's device — the usual case — this is one hipGetDevice.
+struct DeviceScope {
+  int prev = -1, changed = 0;
+  hipError_t enter(int device) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return e;
+    if (prev != device) { e = hipSetDevice(device); changed = (e == hipSuccess); }
+    return e;
+  }
+  ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+};
+
 }  // namespace
 
 struct salp_robot_vec {
@@ -566,7 +580,8 @@ int salp_robot_vec_create(const salp_robot_config_t* cfg, int64_t n_envs, int de
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return rfail(-2, "no HIP device visible (this library has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return rfail(-2, "device_id out of range");
-  RHIP_TRY(hipSetDevice(device_id));
+  DeviceScope dev_scope;
+  RHIP_TRY(dev_scope.enter(device_id));
   salp_robot_vec* h = new (std::nothrow) salp_robot_vec();
   if (!h) return rfail(-4, "host allocation failed");
   memset(h, 0, sizeof(*h));
@@ -603,7 +618,8 @@ int salp_robot_vec_create(const salp_robot_config_t* cfg, int64_t n_envs, int de
 
 void salp_robot_vec_destroy(salp_robot_vec_t* h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DeviceScope dev_scope;
+  (void)dev_scope.enter(h->device);
   if (h->S.f) (void)hipFree(h->S.f);
   if (h->stage) (void)hipFree(h->stage);
   if (h->bins) (void)hipFree(h->bins);
@@ -623,7 +639,8 @@ static int robot_stage(salp_robot_vec* h, size_t bytes) {
 
 int salp_robot_vec_reset(salp_robot_vec_t* h, const uint8_t* mask, float* obs, uint32_t flags, void* stream) {
   if (!h) return rfail(-1, "handle is NULL");
-  RHIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  RHIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((h->n + kRBlock - 1) / kRBlock);
   if (flags & 1u) {
@@ -648,7 +665,8 @@ int salp_robot_vec_reset(salp_robot_vec_t* h, const uint8_t* mask, float* obs, u
 int salp_robot_vec_step(salp_robot_vec_t* h, const float* act, float* obs, float* reward, uint8_t* terminated,
                         uint8_t* truncated, float* final_obs, int32_t* inner_steps, uint32_t flags, void* stream) {
   if (!h || !act) return rfail(-1, "handle / act is NULL");
-  RHIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  RHIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
   if (flags & 1u) return launch_robot_step(h, act, obs, reward, terminated, truncated, final_obs, inner_steps, st);
   const size_t n = (size_t)h->n;
@@ -681,7 +699,8 @@ int salp_robot_vec_step(salp_robot_vec_t* h, const float* act, float* obs, float
 
 int salp_robot_vec_get_state(salp_robot_vec_t* h, double* state, uint32_t flags, void* stream) {
   if (!h || !state) return rfail(-1, "handle / state is NULL");
-  RHIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  RHIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
   // rows are [pitch] on the device and [n] in the snapshot
   RHIP_TRY(hipMemcpy2DAsync(state, (size_t)h->n * sizeof(double), h->S.f, (size_t)h->P.pitch * sizeof(double),

@@ -597,6 +597,21 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
                   std::string(#expr) + ": " + hipGetErrorString(_e));                              \
   } while (0)
 
+
+// Makes `device` current for the scope of one ABI call and restores the caller's device afterwards, so that the
+// library never changes the current HIP device under the caller (PyTorch keeps its own notion of it).  When the
+// caller is already on the handle's device — the usual case — this is one hipGetDevice.
+struct DeviceScope {
+  int prev = -1, changed = 0;
+  hipError_t enter(int device) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return e;
+    if (prev != device) { e = hipSetDevice(device); changed = (e == hipSuccess); }
+    return e;
+  }
+  ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+};
+
 }  // namespace
 
 struct salp_vec {
@@ -825,7 +840,8 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(SALP_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev) return fail(SALP_ERR_NO_DEVICE, "device_id out of range");
-  HIP_TRY(hipSetDevice(device_id));
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(device_id));
 
   salp_vec* h = new (std::nothrow) salp_vec();
   if (!h) return fail(SALP_ERR_OOM, "host allocation failed");
@@ -882,7 +898,8 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
 
 void salp_vec_destroy(salp_vec_t* h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DeviceScope dev_scope;
+  (void)dev_scope.enter(h->device);
   if (h->S.f) (void)hipFree(h->S.f);
   if (h->S.i) (void)hipFree(h->S.i);
   if (h->stats) (void)hipFree(h->stats);
@@ -909,7 +926,8 @@ int32_t salp_vec_base_num_food(const salp_vec_t* h) { return h ? h->P.F_base : 0
 
 int salp_vec_reset(salp_vec_t* h, const uint8_t* mask, float* obs, uint32_t flags, void* stream) {
   if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
   reset_fn fn = reset_kernel_for(h);
@@ -934,7 +952,8 @@ int salp_vec_reset(salp_vec_t* h, const uint8_t* mask, float* obs, uint32_t flag
 
 int salp_vec_observe(salp_vec_t* h, float* obs, uint32_t flags, void* stream) {
   if (!h || !obs) return fail(SALP_ERR_INVALID, "handle/obs is NULL");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
   reset_fn fn = reset_kernel_for(h);
@@ -959,7 +978,8 @@ static int rollout_impl(salp_vec_t* h, const float* act, int32_t H, float* obs, 
                         float* act_out, uint32_t flags, void* stream) {
   if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
   if (H <= 0) return fail(SALP_ERR_INVALID, "horizon must be >= 1");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
   IOPtrs io;
   memset(&io, 0, sizeof(io));
@@ -1042,7 +1062,8 @@ int salp_vec_rollout(salp_vec_t* h, const float* act, int32_t horizon, float* ob
 
 int salp_vec_get_state(salp_vec_t* h, double* f64, int32_t* i32, uint32_t flags, void* stream) {
   if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
   const size_t fb = (size_t)SALP_F_COUNT(h->F) * h->n * sizeof(double);
@@ -1067,7 +1088,8 @@ int salp_vec_get_state(salp_vec_t* h, double* f64, int32_t* i32, uint32_t flags,
 
 int salp_vec_set_state(salp_vec_t* h, const double* f64, const int32_t* i32, uint32_t flags, void* stream) {
   if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
   const size_t fb = (size_t)SALP_F_COUNT(h->F) * h->n * sizeof(double);
@@ -1092,7 +1114,8 @@ int salp_vec_set_state(salp_vec_t* h, const double* f64, const int32_t* i32, uin
 
 int salp_vec_get_stats(salp_vec_t* h, salp_stats_t* out) {
   if (!h || !out) return fail(SALP_ERR_INVALID, "handle/out is NULL");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(h->device));
   HIP_TRY(hipDeviceSynchronize());
   DevStats host[SALP_STATS_REPLICAS];
   HIP_TRY(hipMemcpy(host, h->stats, sizeof(host), hipMemcpyDeviceToHost));
@@ -1109,7 +1132,8 @@ int salp_vec_get_stats(salp_vec_t* h, salp_stats_t* out) {
 
 int salp_vec_clear_stats(salp_vec_t* h) {
   if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
-  HIP_TRY(hipSetDevice(h->device));
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(h->device));
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(h->stats, 0, SALP_STATS_REPLICAS * sizeof(DevStats)));
   return SALP_OK;
