@@ -238,6 +238,7 @@ def main():
     # --gather all: two output blocks, so that the collective of launch k (which reads block k % 2) runs beside
     # launch k + 1 (which writes the other one); a block is only rewritten after its collective has completed
     outs, works = [None, None], [None, None]
+    gather_steps = max(1, min(H, int((2 << 30) // max(1, n * cfg.obs_dim * 4))))   # steps per all-gather piece (<= ~2 GB per rank)
     if senv is not None and gather == "all":
         assert senv.env_index_base == plan["env_index_base"](rank) and senv.local_envs == n
         for b in range(2):
@@ -249,12 +250,19 @@ def main():
         if gather == "all":
             b = k & 1
             if works[b] is not None:
-                works[b].wait()
+                for w_ in works[b]:
+                    w_.wait()
                 works[b] = None
             out = senv.engine.rollout(act, out=outs[b], **rkw)
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
-            _, works[b] = senv.all_gather(f"all_obs{b}", out["obs"].reshape(1, H, n, cfg.obs_dim), async_op=True)
+            # the block goes out in pieces of at most ~2 GB per rank (whole steps): one collective of 12.6 GB per rank
+            # (G = 2) is a message size RCCL is rarely run at; gathered layout [piece][G][steps, N/G, obs_dim]
+            works[b] = []
+            for i, h0 in enumerate(range(0, H, gather_steps)):
+                piece = out["obs"][h0:h0 + gather_steps]
+                _, w_ = senv.all_gather(f"all_obs{b}_{i}", piece.reshape(1, piece.shape[0], n, cfg.obs_dim), async_op=True)
+                works[b].append(w_)
             return ev
         out = senv.engine.rollout(act, **rkw)
         ev = torch.cuda.Event(enable_timing=True)
@@ -266,7 +274,8 @@ def main():
     def drain():
         for b in range(2):
             if works[b] is not None:
-                works[b].wait()
+                for w_ in works[b]:
+                    w_.wait()
                 works[b] = None
         if senv is not None:
             senv.wait_gather()
