@@ -42,7 +42,10 @@ __device__ __forceinline__ void scan_foods_reg(const Env<FMAX>& e, const OffsetL
         const int k = k0 + j;
         if (k < FMAX) {
           const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
-          double d2 = dx * dx + dy * dy;                 // NaN for an empty slot
+          // CAPTURE (the pass that decides a capture, snake:204-217): the reference's two products and their sum.
+          // Otherwise the value only orders the foods (to 16 ulp, see the packed keys) and feeds fp32 outputs:
+          // one product folded into an fma (<= 1 ulp from the reference's value, one VALU instruction fewer).
+          double d2 = CAPTURE ? (dx * dx + dy * dy) : fma(dy, dy, dx * dx);   // NaN for an empty slot
           if (CAPTURE) {
             const bool hit = !collected && (d2 < cr2);   // NaN never hits
             collected = collected || hit;
