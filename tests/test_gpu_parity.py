@@ -84,6 +84,8 @@ CASES = {
     "free_breathing": dict(preset="single_food", forced_breathing=False),
     "no_respawn_F3": dict(preset="sac_gail", num_food_items=3, respawn_food=False),
     "random_count_F5": dict(preset="sac_gail", num_food_items=5, random_food_count=True),
+    "class_default_F5": dict(preset="sac_gail", num_food_items=5),          # the 8-slot register-food instantiation
+    "F8_all_slots": dict(preset="sac_gail", num_food_items=8, max_steps_without_food=150),
     "K2_generic": dict(preset="sac_gail", num_food_items=6, max_observed_food=2, proximity_reward_weight=2.0),
     "K0_no_food_obs": dict(preset="single_food", max_observed_food=0),
     "F0_empty": dict(preset="single_food", num_food_items=0),

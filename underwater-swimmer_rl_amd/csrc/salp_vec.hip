@@ -168,6 +168,17 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
     lds_off[j] = (!RAGGED || f < rows * Q) ? (r * PITCH + 4 * (SWZ ? (c ^ ((r >> 2) & 1)) : c)) : -1;
   }
 
+#ifdef SALP_EXP_PACKED_PLAN
+  uint32_t plan_pk[3] = {0u, 0u, 0u};
+  if constexpr (!RAGGED && QMAX == 6) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const uint32_t off = (uint32_t)((wave * kWave * PITCH + lds_off[j]) * 4);
+      plan_pk[j >> 1] |= off << (16 * (j & 1));
+    }
+    asm volatile("" : "+v"(plan_pk[0]), "+v"(plan_pk[1]), "+v"(plan_pk[2]));   // keep the packed form: do not re-derive the six
+  }
+#endif
   // Event statistics (episodes, terminations, food, ...) change on rare steps only: they are
   // accumulated with LDS integer atomics inside the rare-event branch instead of living in VGPRs.
   __shared__ unsigned long long blk_stats[16];
@@ -409,6 +420,15 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
       {
         // write-once stream far larger than L2 / Infinity Cache: non-temporal stores (measured -2.4 %)
         v4f tv[QMAX];
+#ifdef SALP_EXP_PACKED_PLAN   // experiment: the six flush offsets as three packed VGPRs (two 16-bit byte offsets each)
+        if constexpr (!RAGGED && QMAX == 6) {
+#pragma unroll
+          for (int j = 0; j < QMAX; ++j) {
+            const uint32_t off = (j & 1) ? (plan_pk[j >> 1] >> 16) : (plan_pk[j >> 1] & 0xFFFFu);
+            tv[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(lds) + off);
+          }
+        } else
+#endif
 #pragma unroll
         for (int j = 0; j < QMAX; ++j)
           if (j < Q && (!RAGGED || lds_off[j] >= 0)) tv[j] = *reinterpret_cast<const v4f*>(tile + lds_off[j]);
@@ -718,6 +738,7 @@ rollout_fn rollout_kernel_for(const salp_vec* h, bool full, bool gen) {
   if (h->kmax == 3 && h->std_consts) {
     if (h->fmax == 1) return pick_rollout<1, 3, true, RAGGED>(forced, full, gen);
     if (h->fmax == 4) return pick_rollout<4, 3, true, RAGGED>(forced, full, gen);
+    if (h->fmax == 8) return pick_rollout<8, 3, true, RAGGED>(forced, full, gen);
     if (h->fmax == 12) return pick_rollout<12, 3, true, RAGGED>(forced, full, gen);
     return pick_rollout<16, 3, true, RAGGED>(forced, full, gen);
   }
@@ -728,6 +749,7 @@ reset_fn reset_kernel_for(const salp_vec* h) {
   if (h->kmax == 3 && h->std_consts) {
     if (h->fmax == 1) return (reset_fn)salp_reset_kernel<1, 3, true>;
     if (h->fmax == 4) return (reset_fn)salp_reset_kernel<4, 3, true>;
+    if (h->fmax == 8) return (reset_fn)salp_reset_kernel<8, 3, true>;
     if (h->fmax == 12) return (reset_fn)salp_reset_kernel<12, 3, true>;
     return (reset_fn)salp_reset_kernel<16, 3, true>;
   }
@@ -850,8 +872,8 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
   h->F = cfg->num_food_items; h->K = cfg->max_observed_food;
   h->obs_dim = 10 + 4 * h->K + 2; h->act_dim = cfg->forced_breathing ? 1 : 2;
   h->kmax = (h->K == 3) ? 3 : 8;
-  // food slots held in registers: 1 (single_food*.yaml), 4, 12 (defaults.yaml / sac_gail.yaml), 16
-  h->fmax = (h->kmax == 3) ? (h->F <= 1 ? 1 : (h->F <= 4 ? 4 : (h->F <= 12 ? 12 : 16))) : 16;
+  // food slots of the kernel instantiation: 1 (single_food*.yaml), 4, 8 (the class default of 5 foods), 12 (sac_gail.yaml), 16
+  h->fmax = (h->kmax == 3) ? (h->F <= 1 ? 1 : (h->F <= 4 ? 4 : (h->F <= 8 ? 8 : (h->F <= 12 ? 12 : 16)))) : 16;
   const int64_t pitch = (int64_t)align_up((size_t)n_envs, 64);
   h->P = make_params(*cfg, n_envs, pitch, seed, env_index_base);
   h->std_consts = is_std(h->P) ? 1 : 0;
