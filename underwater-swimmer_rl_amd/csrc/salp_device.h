@@ -466,9 +466,11 @@ __device__ __forceinline__ ThrustTerms jet_thrust_terms(double th, double noz, d
     t.by = mul_s(ss * S, TT[TT_K008]);
   }
   {  // jitter at fl(phi + d), d = fl((u - 0.5) * 0.05); one Philox block of the env's draw stream (counter rng)
-    uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
+    uint32_t k0 = P.seed_lo, k1 = P.seed_hi, g0 = (uint32_t)genv;
     asm volatile("" : "+s"(k0), "+s"(k1));    // see next_block
-    const U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), rng, 0u, k0, k1);
+    asm volatile("" : "+v"(g0));              // likewise the first-round product 0xD2511F53 * env_lo: one v_mad_u64_u32 here
+                                              // instead of a 64-bit VGPR pair held across the step loop
+    const U4 w = philox4x32_10(g0, (uint32_t)(genv >> 32), rng, 0u, k0, k1);
     const double u = u53(w.x, w.y);
     const double d = mul_s(u - 0.5, TT[TT_K005]);
     const double na = phi + d;

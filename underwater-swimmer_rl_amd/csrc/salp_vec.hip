@@ -139,12 +139,16 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_W
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
-  const int wave = tid / kWave;
+  // the wavefront number and everything derived from it (first env, row bases, tile address) as scalars: index
+  // arithmetic then is a scalar base plus the lane, not 64-bit vector registers held across the loop
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   const int64_t env0 = env_begin + (int64_t)blockIdx.x * kBlock + (int64_t)wave * kWave;  // first env of this wavefront
   const int64_t env = env0 + lane;
   const int rows = (int)((env_end - env0) < kWave ? ((env_end - env0) > 0 ? (env_end - env0) : 0) : kWave);
   const bool active = RAGGED ? (env < env_end) : true;     // !RAGGED: rows is 64 or 0
-  const int64_t envc = (env < env_end) ? env : (env_end - 1);
+  // the env whose state the lane loads: its own — clamped into the range for the lanes past the end (RAGGED), or the
+  // range's first wavefront for a whole wavefront past the end (!RAGGED; it runs no step and stores nothing)
+  const int64_t envc = RAGGED ? ((env < env_end) ? env : (env_end - 1)) : ((rows > 0 ? env0 : env_begin) + lane);
   const uint64_t genv = P.env_base + (uint64_t)envc;
   const int K = (KMAX == 3) ? 3 : P.K;
   const int Q = 3 + K;
