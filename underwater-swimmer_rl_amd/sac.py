@@ -264,7 +264,7 @@ class SAC:
         c = self.__dict__.setdefault("_carry", {})
         for k, v in kw.items():
             if k in c and c[k].shape == v.shape:
-                c[k].copy_(v)
+                c[k].copy_(v.detach())       # values only: nothing of the autograd graph crosses a stage
             else:
                 c[k] = v.detach().clone()
 
