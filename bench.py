@@ -253,6 +253,8 @@ def main():
                 for w_ in works[b]:
                     w_.wait()
                 works[b] = None
+            st = torch.cuda.Event(enable_timing=True)
+            st.record()                      # after the wait for this block's previous collective: the kernel alone
             out = senv.engine.rollout(act, out=outs[b], **rkw)
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -263,13 +265,15 @@ def main():
                 piece = out["obs"][h0:h0 + gather_steps]
                 _, w_ = senv.all_gather(f"all_obs{b}_{i}", piece.reshape(1, piece.shape[0], n, cfg.obs_dim), async_op=True)
                 works[b].append(w_)
-            return ev
+            return st, ev
+        st = torch.cuda.Event(enable_timing=True)
+        st.record()
         out = senv.engine.rollout(act, **rkw)
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         if gather == "final":   # staged + double-buffered: the next launch starts at once, the collective runs beside it
             senv.gather_final_async(out["obs"][-1])
-        return ev
+        return st, ev
 
     def drain():
         for b in range(2):
@@ -296,10 +300,10 @@ def main():
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for k in range(K):
-        starts[k].record()
         if senv is not None:
-            ends[k] = sharded_launch(k)
+            starts[k], ends[k] = sharded_launch(k)
         else:
+            starts[k].record()
             env.rollout(act, **rkw)
             ends[k] = torch.cuda.Event(enable_timing=True)
             ends[k].record()
