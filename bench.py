@@ -173,6 +173,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sac-probe", action="store_true", help="skip the configs[4] first-food-capture probe")
+    ap.add_argument("--no-alt-modes", action="store_true", help="--gpus G > 1: do not also time --gather final / none after the headline")
     ap.add_argument("--sac-probe", action="store_true", help="--gpus G > 1: run the configs[4] probe data-parallel on every rank "
                     "(off by default there: that path — graph segments + RCCL gradient all-reduces — is covered by gloo and "
                     "world-size-1 tests only, and a scaling run must not depend on it)")
@@ -246,7 +247,7 @@ def main():
                            terminated=torch.empty((H, n), dtype=torch.uint8, device=device),
                            truncated=torch.empty((H, n), dtype=torch.uint8, device=device))
 
-    def sharded_launch(k):
+    def sharded_launch(k, gather=gather):
         if gather == "all":
             b = k & 1
             if works[b] is not None:
@@ -378,6 +379,34 @@ def main():
             "note": "the all-gather of every returned observation moves (G-1) x chunk x N/G x obs_dim x 4 B into each rank per "
                     "launch: the whole-job value is the exchange's rate when that exceeds the kernel time (DESIGN.md §7)",
         }
+    if senv is not None and gather == "all" and world > 1 and not args.no_alt_modes:
+        # The same launches with the two lighter exchanges, outside the headline's timed region (K // 2 launches each,
+        # same barrier / max-over-ranks protocol): what the sharded simulator does when not every observation has
+        # to cross xGMI.  Reported beside `value`, never instead of it.
+        alt = {}
+        try:
+            for mode in ("final", "none"):
+                K2 = max(3, K // 2)
+                for k in range(2):
+                    sharded_launch(k, mode)
+                drain()
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                for k in range(K2):
+                    sharded_launch(k, mode)
+                drain()
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                torch.cuda.synchronize(device)
+                e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+                dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+                alt[mode] = {"value": float(world) * n * H * K2 / float(e2.item()), "steps": K2,
+                             "ms_per_step": float(e2.item()) / K2 * 1e3}
+        except Exception as e:   # noqa: BLE001 — the headline line must not be lost to the extras
+            alt["error"] = f"{type(e).__name__}: {e}"
+        line["other_exchange_modes"] = alt
     if not args.no_sac_probe and not rehearsal and not force_sharded and (world == 1 or args.sac_probe):
         probe = sac_first_capture(device, world if senv is not None else 1, rank)   # every rank takes part (collectives)
         line["sac_first_capture"] = probe
