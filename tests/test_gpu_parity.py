@@ -86,6 +86,11 @@ CASES = {
     "random_count_F5": dict(preset="sac_gail", num_food_items=5, random_food_count=True),
     "class_default_F5": dict(preset="sac_gail", num_food_items=5),          # the 8-slot register-food instantiation
     "F8_all_slots": dict(preset="sac_gail", num_food_items=8, max_steps_without_food=150),
+    # K = 3 with non-default constants: the per-slot-count instantiations that read their constants from the launch parameters
+    "other_tank_F1": dict(preset="single_food", width=900, height=700, tank_margin=40.0),
+    "other_physics_F12": dict(preset="sac_gail", drag_coefficient=0.97, max_thrust_force=120.0, base_radius=26.0,
+                              inhale_duration=100, exhale_duration=130, nozzle_response_rate=0.08),
+    "other_tank_F5_free": dict(preset="sac_gail", num_food_items=5, width=1000, forced_breathing=False, min_food_distance=60.0),
     "K2_generic": dict(preset="sac_gail", num_food_items=6, max_observed_food=2, proximity_reward_weight=2.0),
     "K0_no_food_obs": dict(preset="single_food", max_observed_food=0),
     "F0_empty": dict(preset="single_food", num_food_items=0),

@@ -731,32 +731,38 @@ rollout_fn pick_rollout(bool forced, bool full, bool gen) {
               : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, false, RAGGED, false>;
 }
 
-// Literal-constant kernels exist for the reference's constants with K = 3 (every preset); any
-// other configuration runs the generic instantiation (runtime constants, F <= 16, K <= 8).
+// K = 3 (every preset): kernels by food-slot count, with the reference's constants as literals (STD) or — any other
+// tank size, radius, drag, thrust, timing — with the constants read from the launch parameters.  K != 3 runs the
+// generic instantiation (runtime constants, F <= 16, K <= 8, foods in LDS).
 // True when in-kernel action generation is available for this handle and output signature.
-bool can_generate_in_kernel(const salp_vec* h, bool full) { return full && h->kmax == 3 && h->std_consts; }
+bool can_generate_in_kernel(const salp_vec* h, bool full) { return full && h->kmax == 3; }
 
+template <bool STD, bool RAGGED>
+rollout_fn rollout_kernel_k3(const salp_vec* h, bool forced, bool full, bool gen) {
+  if (h->fmax == 1) return pick_rollout<1, 3, STD, RAGGED>(forced, full, gen);
+  if (h->fmax == 4) return pick_rollout<4, 3, STD, RAGGED>(forced, full, gen);
+  if (h->fmax == 8) return pick_rollout<8, 3, STD, RAGGED>(forced, full, gen);
+  if (h->fmax == 12) return pick_rollout<12, 3, STD, RAGGED>(forced, full, gen);
+  return pick_rollout<16, 3, STD, RAGGED>(forced, full, gen);
+}
 template <bool RAGGED>
 rollout_fn rollout_kernel_for(const salp_vec* h, bool full, bool gen) {
   const bool forced = h->P.forced != 0;
-  if (h->kmax == 3 && h->std_consts) {
-    if (h->fmax == 1) return pick_rollout<1, 3, true, RAGGED>(forced, full, gen);
-    if (h->fmax == 4) return pick_rollout<4, 3, true, RAGGED>(forced, full, gen);
-    if (h->fmax == 8) return pick_rollout<8, 3, true, RAGGED>(forced, full, gen);
-    if (h->fmax == 12) return pick_rollout<12, 3, true, RAGGED>(forced, full, gen);
-    return pick_rollout<16, 3, true, RAGGED>(forced, full, gen);
-  }
+  if (h->kmax == 3)
+    return h->std_consts ? rollout_kernel_k3<true, RAGGED>(h, forced, full, gen) : rollout_kernel_k3<false, RAGGED>(h, forced, full, gen);
   return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, false, RAGGED, false>
                 : (rollout_fn)salp_rollout_kernel<16, 8, false, false, false, RAGGED, false>;
 }
+template <bool STD>
+reset_fn reset_kernel_k3(const salp_vec* h) {
+  if (h->fmax == 1) return (reset_fn)salp_reset_kernel<1, 3, STD>;
+  if (h->fmax == 4) return (reset_fn)salp_reset_kernel<4, 3, STD>;
+  if (h->fmax == 8) return (reset_fn)salp_reset_kernel<8, 3, STD>;
+  if (h->fmax == 12) return (reset_fn)salp_reset_kernel<12, 3, STD>;
+  return (reset_fn)salp_reset_kernel<16, 3, STD>;
+}
 reset_fn reset_kernel_for(const salp_vec* h) {
-  if (h->kmax == 3 && h->std_consts) {
-    if (h->fmax == 1) return (reset_fn)salp_reset_kernel<1, 3, true>;
-    if (h->fmax == 4) return (reset_fn)salp_reset_kernel<4, 3, true>;
-    if (h->fmax == 8) return (reset_fn)salp_reset_kernel<8, 3, true>;
-    if (h->fmax == 12) return (reset_fn)salp_reset_kernel<12, 3, true>;
-    return (reset_fn)salp_reset_kernel<16, 3, true>;
-  }
+  if (h->kmax == 3) return h->std_consts ? reset_kernel_k3<true>(h) : reset_kernel_k3<false>(h);
   return (reset_fn)salp_reset_kernel<16, 8, false>;
 }
 
