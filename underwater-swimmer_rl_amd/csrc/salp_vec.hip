@@ -93,7 +93,7 @@ struct ColdBlock {
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
 template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? SALP_MULTI_WAVES : 1))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ? SALP_MULTI_WAVES : 2) : 1))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
   // LDS tile of the wavefront's 64 observation rows.  Banking (MI355X_MICROARCH.md §LDS): ds_write_b128 goes
   // in 8 groups of 8 lanes over banks (a/4) mod 32, ds_read_b128 in 4 groups of 16 lanes ({0-3,12-15,20-27},
@@ -750,6 +750,9 @@ rollout_fn rollout_kernel_for(const salp_vec* h, bool full, bool gen) {
   const bool forced = h->P.forced != 0;
   if (h->kmax == 3)
     return h->std_consts ? rollout_kernel_k3<true, RAGGED>(h, forced, full, gen) : rollout_kernel_k3<false, RAGGED>(h, forced, full, gen);
+  if (h->fmax <= 12)   // K != 3 with up to 12 foods: the register-food form of the generic instantiation (2 wavefronts per SIMD, not 1)
+    return forced ? (rollout_fn)salp_rollout_kernel<12, 8, true, false, false, RAGGED, false>
+                  : (rollout_fn)salp_rollout_kernel<12, 8, false, false, false, RAGGED, false>;
   return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, false, RAGGED, false>
                 : (rollout_fn)salp_rollout_kernel<16, 8, false, false, false, RAGGED, false>;
 }
@@ -883,7 +886,7 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
   h->obs_dim = 10 + 4 * h->K + 2; h->act_dim = cfg->forced_breathing ? 1 : 2;
   h->kmax = (h->K == 3) ? 3 : 8;
   // food slots of the kernel instantiation: 1 (single_food*.yaml), 4, 8 (the class default of 5 foods), 12 (sac_gail.yaml), 16
-  h->fmax = (h->kmax == 3) ? (h->F <= 1 ? 1 : (h->F <= 4 ? 4 : (h->F <= 8 ? 8 : (h->F <= 12 ? 12 : 16)))) : 16;
+  h->fmax = (h->kmax == 3) ? (h->F <= 1 ? 1 : (h->F <= 4 ? 4 : (h->F <= 8 ? 8 : (h->F <= 12 ? 12 : 16)))) : (h->F <= 12 ? 12 : 16);
   const int64_t pitch = (int64_t)align_up((size_t)n_envs, 64);
   h->P = make_params(*cfg, n_envs, pitch, seed, env_index_base);
   h->std_consts = is_std(h->P) ? 1 : 0;
