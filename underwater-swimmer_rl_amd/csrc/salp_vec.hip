@@ -422,7 +422,6 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       if (rows < 0)
 #endif
       {
-        // write-once stream far larger than L2 / Infinity Cache: non-temporal stores (measured -2.4 %)
         v4f tv[QMAX];
 #ifdef SALP_EXP_PACKED_PLAN   // experiment: the six flush offsets as three packed VGPRs (two 16-bit byte offsets each)
         if constexpr (!RAGGED && QMAX == 6) {
@@ -436,6 +435,23 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
 #pragma unroll
         for (int j = 0; j < QMAX; ++j)
           if (j < Q && (!RAGGED || lds_off[j] >= 0)) tv[j] = *reinterpret_cast<const v4f*>(tile + lds_off[j]);
+        // Write-once stream far larger than L2 / Infinity Cache.  The unpredicated one-food K = 3 kernels issue the row stores
+        // as `global_store_dwordx4 ... sc1 nt` — system scope (written through, not retained in L2) plus the
+        // streaming hint: measured -4.2 % on the one-food kernel against `nt` alone, which is what
+        // __builtin_nontemporal_store emits and what was -2.4 % against plain stores (profiles/r02/ab_notes.md
+        // session 14).  The compiler has no builtin for the scope bits of a plain global store, hence the asm; its
+        // waitcnt pass does not count these stores, which is safe: vmcnt retires in order, so a wait computed
+        // without them can only wait longer, and nothing reads the stream back.
+#ifndef SALP_OBS_STORE_BITS
+#define SALP_OBS_STORE_BITS "sc1 nt"
+#endif
+        if constexpr (!RAGGED && QMAX == 6 && !MULTI) {   // the write-bound one-food kernel; the VALU-bound multi-food ones: +1 %, not used
+          v4f* const gout4 = gout + 4 * kWave;     // the instruction's immediate offset reaches 4095 B: two bases
+#pragma unroll
+          for (int j = 0; j < QMAX; ++j)
+            asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " SALP_OBS_STORE_BITS
+                         :: "v"(j < 4 ? gout : gout4), "v"(tv[j]), "n"((j & 3) * kWave * 16) : "memory");
+        } else
 #pragma unroll
         for (int j = 0; j < QMAX; ++j)
           if (j < Q && (!RAGGED || lds_off[j] >= 0)) __builtin_nontemporal_store(tv[j], &gout[j * kWave]);
