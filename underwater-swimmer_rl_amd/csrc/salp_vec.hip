@@ -293,9 +293,20 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       // reward: one dword per lane (256 B per wavefront); flags: one byte per lane.  (Rebuilding the
       // 64 flag bytes from a ballot and storing 16 dwords was measured: no faster in the memory
       // pipeline and slower overall, profiles/r01/ab_notes.md.)
+#ifdef SALP_EXP_SMALL_STORE_BITS   // experiment: cache-policy bits of the reward / flag stores (FULL, unpredicated kernels)
+      if constexpr (FULL && !RAGGED) {
+        const float rv = o.reward;
+        const int tv_ = o.terminated ? 1 : 0, uv_ = o.truncated ? 1 : 0;
+        asm volatile("global_store_dword %0, %1, off " SALP_EXP_SMALL_STORE_BITS :: "v"(&io.reward[rowbase + env]), "v"(rv) : "memory");
+        asm volatile("global_store_byte %0, %1, off " SALP_EXP_SMALL_STORE_BITS :: "v"(&io.terminated[rowbase + env]), "v"(tv_) : "memory");
+        asm volatile("global_store_byte %0, %1, off " SALP_EXP_SMALL_STORE_BITS :: "v"(&io.truncated[rowbase + env]), "v"(uv_) : "memory");
+      } else
+#endif
+      {
       if (FULL || io.reward) io.reward[rowbase + env] = o.reward;
       if (FULL || io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
       if (FULL || io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
+      }
       if (!FULL && io.info) {
         int32_t* ip = io.info + (rowbase + env) * SALP_INFO_COLS;
         ip[SALP_INFO_FOOD_COLLECTED] = e.fc;
