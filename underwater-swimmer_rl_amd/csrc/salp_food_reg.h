@@ -2,21 +2,25 @@
 // defaults.yaml, 12 in sac_gail.yaml), with the food positions of an env in VGPRs.
 //
 // The LDS-resident form (salp_food_lds.h, still used above 12 slots and by the generic instantiation) costs
-// 16 B x slots x 64 lanes of LDS per wavefront: with 12 slots 12 KB, which caps the CU at 8 wavefronts
-// (2 per SIMD), and the kernel is issue-bound with the VALU ~58 % busy at that residency.  Since the step loop
-// no longer keeps ~45 VGPRs of hoisted constants (build.py: no machine LICM) the 48 VGPRs of 12 positions fit
-// under the 168-VGPR budget of 3 wavefronts per SIMD.  What registers cannot do is per-lane dynamic indexing —
-// the K selected foods are only known as slot numbers after the pass — so the pass leaves each slot's fp32
-// offset (dx, dy) in a small per-wavefront LDS block (8 B per slot and lane, half the LDS of the positions,
-// written once per slot and step, read K times), and the selection reads its K offsets from there.  The
-// arithmetic on each food is the reference's, in its order, exactly as in salp_food_lds.h.
+// 16 B x slots x 64 lanes of LDS per wavefront for the whole launch: with 12 slots 12 KB next to the 6 KB
+// observation tile, which caps the CU at 8 wavefronts (2 per SIMD), and the kernel is issue-bound with the VALU
+// ~58 % busy at that residency.  Since the step loop no longer keeps ~45 VGPRs of hoisted constants (build.py: no
+// machine LICM) the 48 VGPRs of 12 positions fit under the 168-VGPR budget of 3 wavefronts per SIMD.  What
+// registers cannot do is per-lane dynamic indexing — the K selected foods are only known as slot numbers after
+// the pass — so the pass leaves each slot's offset (dx, dy) in a per-wavefront LDS block that lives only from the
+// pass to the selection and shares its bytes with the observation tile (salp_vec.hip), written once per slot and
+// step, read K times.  The offsets are stored as the fp64 pair the pass has in registers (one ds_write_b128,
+// 12 KB per wavefront = 48 KB per workgroup, three workgroups per CU) and narrowed to fp32 for the K selected
+// slots only: storing fp32 pairs took two v_cvt_f32_f64 per slot and step, 24 of the kernel's ~680 VALU
+// instructions per wavefront-step, for values of which 3 are read (profiles/r02/ab_notes.md session 15).
+// The arithmetic on each food is the reference's, in its order, exactly as in salp_food_lds.h.
 #pragma once
 #include "salp_food_lds.h"
 
 namespace salp {
 
 struct OffsetLds {
-  float2* col;   // this lane's column of the wavefront's [FMAX][64] block of (dx, dy) in fp32
+  double2* col;   // this lane's column of the wavefront's [FMAX][64] block of (dx, dy)
 };
 
 // One pass over the slots (see scan_foods in salp_food_lds.h for CAPTURE / COUNT).  Groups of four slots
@@ -36,7 +40,7 @@ __device__ __forceinline__ void scan_foods_reg(const Env<FMAX>& e, const OffsetL
   hit_k = 0;
 #pragma unroll
   for (int k0 = 0; k0 < FMAX; k0 += 4) {
-    if (k0 < F) {
+    if (k0 == 0 || k0 < F) {   // the first group always runs (its slots beyond F are empty): it fills the list
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = k0 + j;
@@ -55,13 +59,27 @@ __device__ __forceinline__ void scan_foods_reg(const Env<FMAX>& e, const OffsetL
           if (COUNT) n += (d2 == d2) ? 1 : 0;
           if (ALLLIVE) dsum += __builtin_amdgcn_sqrtf((float)d2);
           else dsum += __builtin_fmaxf(__builtin_amdgcn_sqrtf((float)d2), 0.f);   // maxnum: NaN (empty) adds 0
-          sc.col[k * kFoodLanes] = make_float2((float)dx, (float)dy);
+          sc.col[k * kFoodLanes] = make_double2(dx, dy);
           double cv = pack_key(ALLLIVE ? d2 : min_key_s(d2, dead), k);
+          if (k < KMAX) {
+            // slots 0..KMAX-1 fill the list: entries k.. are still empty (= larger than any key), so slot k is
+            // inserted among k entries — 0, 2, 4 min/max instead of 5 each for K = 3
 #pragma unroll
-          for (int s = 0; s < KMAX; ++s) {
-            const double lo = min_key(cv, q.key[s]);
-            if (s + 1 < KMAX) cv = max_key(cv, q.key[s]);
-            q.key[s] = lo;
+            for (int s = 0; s < KMAX; ++s) {
+              if (s < k) {
+                const double lo = min_key(cv, q.key[s]);
+                cv = max_key(cv, q.key[s]);
+                q.key[s] = lo;
+              }
+            }
+            q.key[k < KMAX ? k : 0] = cv;
+          } else {
+#pragma unroll
+            for (int s = 0; s < KMAX; ++s) {
+              const double lo = min_key(cv, q.key[s]);
+              if (s + 1 < KMAX) cv = max_key(cv, q.key[s]);
+              q.key[s] = lo;
+            }
           }
         }
       }
@@ -71,8 +89,9 @@ __device__ __forceinline__ void scan_foods_reg(const Env<FMAX>& e, const OffsetL
   if (COUNT) cnt = n;
 }
 
-// fp32 geometry of the first K selected foods: the offsets the pass left in LDS, the distance from the key
-// (the squared distance to within 16 ulp of fp64: the same float except on ~3e-8 of the values, then 1 ulp).
+// fp32 geometry of the first K selected foods: the offsets the pass left in LDS, narrowed here (the reference's
+// float32 cast of the fp64 difference), the distance from the key (the squared distance to within 16 ulp of fp64:
+// the same float except on ~3e-8 of the values, then 1 ulp).
 template <int KMAX>
 __device__ __forceinline__ void resolve_reg(const OffsetLds& sc, int K, FoodScan<KMAX>& q) {
 #pragma unroll
@@ -81,10 +100,10 @@ __device__ __forceinline__ void resolve_reg(const OffsetLds& sc, int K, FoodScan
     if (s < K) {
       const int k = key_slot(q.key[s]);
       const bool found = key_found(q.key[s]);
-      const float2 o = sc.col[k * kFoodLanes];
+      const double2 o = sc.col[k * kFoodLanes];
       q.idx[s] = found ? k : -1;
-      q.bx[s] = found ? o.x : 0.f;
-      q.by[s] = found ? o.y : 0.f;
+      q.bx[s] = found ? (float)o.x : 0.f;
+      q.by[s] = found ? (float)o.y : 0.f;
       q.bd[s] = found ? __builtin_amdgcn_sqrtf((float)q.key[s]) : 0.f;
     }
   }

@@ -107,7 +107,6 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   constexpr bool SWZ = (KMAX == 3);
 #endif
   constexpr int PITCH = SWZ ? 4 * QMAX : 4 * QMAX + 4;     // LDS row pitch in floats
-  __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * kWave * PITCH];
   // Where the food positions of a multi-food env live: up to 12 slots in VGPRs (salp_food_reg.h: the pass
   // leaves fp32 offsets in a small LDS block), above that in LDS (salp_food_lds.h); one food is plain registers.
 #ifdef SALP_EXP_LDS_FOOD      // experiment build: the LDS-resident form for every multi-food kernel
@@ -119,9 +118,12 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
 #endif
   constexpr bool MULTI = REGF || LDSF;
   __shared__ __attribute__((aligned(16))) double2 food_lds[LDSF ? (kBlock / kWave) * FMAX * kWave : 1];
-  // The fp32 offsets of the register-food pass live for the middle of a step (pass -> selection), the observation
-  // tile for its end (row writes -> flush): with 12 slots both are 6144 B per wavefront and share the same bytes
-  // (LDS operations of a wavefront execute in order; a wavefront fence separates the two uses for the compiler).
+  // Per-wavefront LDS region: the observation tile (64 rows) — and, for the register-food kernels, the (dx, dy)
+  // offsets of the pass (16 B per slot and lane, salp_food_reg.h) in the SAME bytes: the offsets live for the middle
+  // of a step (pass -> selection), the tile for its end (row writes -> flush).  LDS operations of a wavefront
+  // execute in order; a wavefront fence separates the two uses for the compiler.  12 slots: 12288 B per wavefront.
+  constexpr int WAVE_FLOATS = (REGF && 4 * FMAX > PITCH) ? kWave * 4 * FMAX : kWave * PITCH;
+  __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * WAVE_FLOATS];
 #ifdef SALP_EXP_POOL   // experiment build: block-pooled thrust (salp_device.h ThrustPool) in whole-workgroup launches of
   // the register-food kernels.  Bit-identical results, a quarter of the thrust instructions — and 35 % SLOWER
   // (2.85 against 2.12 ms, profiles/r02/ab_notes.md session 6): the two workgroup barriers per step put the four
@@ -134,8 +136,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   __shared__ __attribute__((aligned(16))) double pool_out[POOL ? 7 * kPoolN : 1];
   __shared__ __attribute__((aligned(8))) uint2 pool_meta[POOL ? kPoolN : 1];
   __shared__ unsigned pool_count[2];
-  constexpr bool ALIAS_OFFS = REGF && (2 * FMAX <= PITCH);
-  __shared__ __attribute__((aligned(16))) float2 off_lds[(REGF && !ALIAS_OFFS) ? (kBlock / kWave) * FMAX * kWave : 1];
+  constexpr bool ALIAS_OFFS = REGF;
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   const int Q = 3 + K;
   const int OD = 4 * Q;
   const int AD = FORCED ? 1 : 2;
-  float* tile = lds + wave * kWave * PITCH;
+  float* tile = lds + wave * WAVE_FLOATS;
   float4* myrow4 = reinterpret_cast<float4*>(tile + lane * PITCH);
   // SWZ: column q of this lane's row sits at float4 (q ^ s), s = bit 2 of the row = q + s for even q, q - s for odd q
   const int swz = SWZ ? ((lane >> 2) & 1) : 0;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   if constexpr (!RAGGED && QMAX == 6) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const uint32_t off = (uint32_t)((wave * kWave * PITCH + lds_off[j]) * 4);
+      const uint32_t off = (uint32_t)((wave * WAVE_FLOATS + lds_off[j]) * 4);
       plan_pk[j >> 1] |= off << (16 * (j & 1));
     }
     asm volatile("" : "+v"(plan_pk[0]), "+v"(plan_pk[1]), "+v"(plan_pk[2]));   // keep the packed form: do not re-derive the six
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   using EnvT = std::conditional_t<LDSF, EnvCore, Env<FMAX>>;
   EnvT e;
   const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
-  const OffsetLds offs{ALIAS_OFFS ? (reinterpret_cast<float2*>(tile) + lane) : (off_lds + (REGF ? (wave * FMAX * kWave + lane) : 0))};
+  const OffsetLds offs{reinterpret_cast<double2*>(tile) + lane};   // REGF only
   FoodScan<KMAX> fq;          // MULTI: nearest-K selection of the current food set around the current pose
   int nlive = 0;              // MULTI: live foods of this env, recounted whenever the food set changes
   if constexpr (LDSF) {
