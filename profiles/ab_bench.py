@@ -54,7 +54,12 @@ def main():
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record(); launch(name); e.record(); e.synchronize()
                 times[name].append(s.elapsed_time(e))
-    out = {name: {"median_ms": statistics.median(t), "min_ms": min(t), "max_ms": max(t), "n": len(t)} for name, t in times.items()}
+    # every variant simulates the same trajectory (same seed, warm-up and launch count), so launch i of one variant and
+    # launch i of another do the same work: the MEAN over all launches, and the mean of the per-launch ratios to the
+    # first variant, compare like with like even though launches differ from each other (event rates drift)
+    base = times[variants[0][0]]
+    out = {name: {"median_ms": statistics.median(t), "mean_ms": statistics.fmean(t), "min_ms": min(t), "max_ms": max(t), "n": len(t),
+                  "paired_ratio_to_first": statistics.fmean(a / b for a, b in zip(t, base))} for name, t in times.items()}
     if os.environ.get("AB_DUMP") == "1":   # every launch time in order (e.g. with AB_WARM=0: the phase mix desynchronising)
         for name, t in times.items():
             out[name]["all_ms"] = [round(x, 4) for x in t]

@@ -18,6 +18,22 @@
 
 namespace salp {
 
+// ---- in-kernel phase stamps (experiment build -DSALP_EXP_STAMPS, profiles/stamp_profile.py) ---------------------
+// Shader-clock stamps (s_memtime) at a few phase boundaries of the step, accumulated per wavefront in scalar
+// registers and written to a debug buffer of their own after the loop: where a wavefront's lifetime goes, stalls
+// included.  No product build executes a stamp.
+#ifdef SALP_EXP_STAMPS
+struct StampAcc { uint32_t last; uint32_t acc[12]; };
+#define SALP_STAMP_PARAM , StampAcc* stamps_ = nullptr
+#define SALP_STAMP_PASS , stamps_
+#define SALP_STAMP(i) do { if (stamps_) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); \
+                                          stamps_->acc[i] += now_ - stamps_->last; stamps_->last = now_; } } while (0)
+#else
+#define SALP_STAMP_PARAM
+#define SALP_STAMP_PASS
+#define SALP_STAMP(i) do {} while (0)
+#endif
+
 // ---- packed breathing word: phase[1:0] | timer[9:2] | exhale_dur[17:10] | shape_hold[20:18]
 __host__ __device__ inline uint32_t pack_breath(int phase, int timer, int dur, int hold) {
   return (uint32_t)(phase & 3) | ((uint32_t)(timer & 255) << 2) | ((uint32_t)(dur & 255) << 10) |
@@ -691,7 +707,7 @@ struct StepOut {
 // legacy:119-156 up to and including the wall bounce; returns r = max(ellipse_a, ellipse_b) of this step.
 template <bool FORCED, bool STD, bool HOIST = false, bool POOL = false>
 __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint64_t genv, float a0, float a1, const HotK& hk = HotK(),
-                                            const ThrustPool* pool = nullptr) {
+                                            const ThrustPool* pool = nullptr SALP_STAMP_PARAM) {
   int phase = bw_phase(e.packed), timer = bw_timer(e.packed), dur = bw_dur(e.packed);
   // legacy:121-135
   double nd;
@@ -779,8 +795,10 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
 #ifdef SALP_EXP_NO_THRUST      // experiment build (profiles/ab_bench.py): price of the thrust block
   thrust = false;
 #endif
+  SALP_STAMP(1);
   if constexpr (POOL) pooled_thrust<STD>(e, P, *pool, thrust, r);     // two workgroup barriers, executed by every lane
   else if (thrust) apply_jet_thrust<1, STD>(e, P, genv, r);
+  SALP_STAMP(2);
   e.water = water_next;
   e.packed = pack_breath(phase, timer, dur, hold);
   // legacy:316-352 _update_physics
@@ -807,6 +825,7 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
     if (e.y < m) { e.y = m; e.vy = fabs(e.vy) * k04; e.om = e.om * k07; }
     else if (e.y > hy) { e.y = hy; e.vy = -fabs(e.vy) * k04; e.om = e.om * k07; }
   }
+  SALP_STAMP(3);
   return r;
 }
 

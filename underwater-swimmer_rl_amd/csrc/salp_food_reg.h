@@ -124,11 +124,11 @@ __device__ __forceinline__ void clear_slot(Env<FMAX>& e, bool doit, int k) {
 template <int FMAX, int KMAX, bool FORCED, bool STD, bool HOIST, bool POOL>
 __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& sc, const DevParams& P, const HotK& hk, uint64_t genv,
                                                 float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, const ThrustPool* pool,
-                                                const DevParams* cold) {
+                                                const DevParams* cold SALP_STAMP_PARAM) {
   // `cold`: the device-memory copy of the launch constants (ColdBlock).  The capture bonus and the collision
   // penalty are read from it inside the wave-uniform branches that need them (a few percent of the steps), so
   // their four fp64 constants and two predicate masks do not sit in — and get spilled from — scalar registers.
-  const double r = step_head<FORCED, STD, HOIST, POOL>(e, P, genv, a0, a1, hk, pool);
+  const double r = step_head<FORCED, STD, HOIST, POOL>(e, P, genv, a0, a1, hk, pool SALP_STAMP_PASS);
   StepOut o;
   o.rmax = r;
   const double cr = r + KV(food_radius, CV(food_radius));
@@ -137,6 +137,7 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& s
   bool all_live = (KMAX <= FMAX) && __all(nlive == FMAX);     // wave-uniform; then every lane also has K foods to show
   if (all_live) scan_foods_reg<FMAX, KMAX, false, false, true>(e, sc, P.F, 0.0, q, o.collected, hit_k, cnt_);
   else scan_foods_reg<FMAX, KMAX, false, false>(e, sc, P.F, 0.0, q, o.collected, hit_k, cnt_);
+  SALP_STAMP(4);
   double rew = 0.0;                                              // snake:278-327, terms added in the reference's order
   if (__any(q.key[0] < cr2 * KV(cap_slack, 1.00000000001))) {   // see step_env_lds
     scan_foods_reg<FMAX, KMAX, true, true>(e, sc, P.F, cr2, q, o.collected, hit_k, nlive);
@@ -166,6 +167,7 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& s
   }
   rew += P.time_penalty;
   step_tail(e, P, o, rew, nlive > 0);
+  SALP_STAMP(5);
   return o;
 }
 

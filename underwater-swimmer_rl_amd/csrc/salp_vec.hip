@@ -71,6 +71,11 @@ struct IOPtrs {
   int64_t global_step;    // step index of t = 0 (device-generated actions)
 };
 
+#ifdef SALP_EXP_STAMPS
+constexpr int kStampWaves = 8192;
+__device__ uint32_t salp_stamp_out[kStampWaves * 16];
+#endif
+
 // Device-memory copy of the launch constants for the RARE paths of the rollout kernel (respawn / autoreset
 // region, exact capture pass, state write-back).  Everything the per-step path needs arrives by value in
 // `P` (scalar registers); what only the rare paths read is fetched from this block when they run, so it
@@ -173,6 +178,15 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     lds_off[j] = (!RAGGED || f < rows * Q) ? (r * PITCH + 4 * (SWZ ? (c ^ ((r >> 2) & 1)) : c)) : -1;
   }
 
+  // the six source addresses of the flush as ONE register each: left to itself the compiler keeps the row term and
+  // the swizzled column term of every address in separate registers and adds them on every step
+  const v4f* flush_src[QMAX];
+#pragma unroll
+  for (int j = 0; j < QMAX; ++j) {
+    int i = wave * WAVE_FLOATS + (lds_off[j] >= 0 ? lds_off[j] : 0);
+    asm volatile("" : "+v"(i));
+    flush_src[j] = reinterpret_cast<const v4f*>(lds + i);
+  }
 #ifdef SALP_EXP_PACKED_PLAN
   uint32_t plan_pk[3] = {0u, 0u, 0u};
   if constexpr (!RAGGED && QMAX == 6) {
@@ -241,6 +255,12 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
 #ifdef SALP_EXP_BLOCK_SYNC
   const bool block_full = env_begin + ((int64_t)blockIdx.x + 1) * kBlock <= env_end;
 #endif
+#ifdef SALP_EXP_STAMPS
+  StampAcc stamps;
+  for (int i = 0; i < 12; ++i) stamps.acc[i] = 0u;
+  stamps.last = (uint32_t)__builtin_amdgcn_s_memtime();
+  StampAcc* const stamps_ = &stamps;
+#endif
 #pragma unroll 1
   for (int t = 0; t < Hrun; ++t) {
     const int64_t rowbase = (int64_t)t * P.n;
@@ -279,7 +299,12 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     if constexpr (LDSF) o = step_env_lds<KMAX, FORCED, STD>(e, food, P, genv, c0, c1, K, fq, nlive);
     else if constexpr (REGF) {
       ThrustPool pool{pool_in, pool_out, pool_meta, pool_count, P.env_base + (uint64_t)(env_begin + (int64_t)blockIdx.x * kBlock), wave, lane, t};
+#ifdef SALP_EXP_STAMPS
+      { StampAcc* stamps_ = &stamps; SALP_STAMP(0); }
+      o = step_env_reg<FMAX, KMAX, FORCED, STD, kHoist, POOL>(e, offs, P, hotk, genv, c0, c1, K, fq, nlive, &pool, &cold->P, &stamps);
+#else
       o = step_env_reg<FMAX, KMAX, FORCED, STD, kHoist, POOL>(e, offs, P, hotk, genv, c0, c1, K, fq, nlive, &pool, &cold->P);
+#endif
     }
     else o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
 #endif
@@ -317,6 +342,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     }
     st_reward += (double)o.reward;
 
+    SALP_STAMP(6);
     // rare events: respawn of a collected food (snake:179-180), then same-step autoreset
     int todo = (o.collected && P.respawn) ? 1 : 0;
     const int F_base = P.F_base;
@@ -337,6 +363,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
           atomicAdd(&blk_stats[ST_EPRET], (unsigned long long)__double2ll_rn(e.epret * SALP_FIXED_SCALE));
         }
       }
+      SALP_STAMP(10);
 #pragma unroll 1
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1 && done && C.autoreset) {
@@ -387,6 +414,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
         else place_food<FMAX, STD>(e, C, genv, todo, limit);
         todo = 0;
       }
+      SALP_STAMP(11);
       if constexpr (LDSF) {   // the food set (or the pose) changed: select again for the observation
         bool c_; int h_;
         scan_foods<KMAX, false, true>(food, C.F, e.x, e.y, 0.0, fq, c_, h_, nlive);
@@ -394,12 +422,15 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
         have_rel = false;
       }
       if constexpr (REGF) {
+        // (inserting the one respawned food into the capture pass's list instead of a second pass over all slots
+        // saves ~200 instructions on ~7 % of the steps on paper and measured 0.6-1.7 % SLOWER twice: ab_notes.md session 15)
         bool c_; int h_;
         scan_foods_reg<FMAX, KMAX, false, true>(e, offs, C.F, 0.0, fq, c_, h_, nlive);
         resolve_reg<KMAX>(offs, K, fq);
         have_rel = false;
       }
     }
+    SALP_STAMP(7);
 
     if (FULL || io.obs) {
       float ob[12 + 4 * KMAX];
@@ -409,6 +440,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
         else observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
       } else if constexpr (LDSF) observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
       else observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
+      SALP_STAMP(8);
 #ifdef SALP_EXP_DIRECT_STORE   // experiment: per-lane 96-B rows straight from registers (no LDS transpose)
       if (active) {
         float4* drow = reinterpret_cast<float4*>(io.obs + (rowbase + env) * OD);
@@ -446,7 +478,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
 #endif
 #pragma unroll
         for (int j = 0; j < QMAX; ++j)
-          if (j < Q && (!RAGGED || lds_off[j] >= 0)) tv[j] = *reinterpret_cast<const v4f*>(tile + lds_off[j]);
+          if (j < Q && (!RAGGED || lds_off[j] >= 0)) tv[j] = *flush_src[j];
         // Write-once stream far larger than L2 / Infinity Cache.  The unpredicated one-food K = 3 kernels issue the row stores
         // as `global_store_dwordx4 ... sc1 nt` — system scope (written through, not retained in L2) plus the
         // streaming hint: measured -4.2 % on the one-food kernel against `nt` alone, which is what
@@ -489,7 +521,14 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
 #ifdef SALP_EXP_BLOCK_SYNC
     if (block_full) __syncthreads();
 #endif
+    SALP_STAMP(9);
   }
+#ifdef SALP_EXP_STAMPS
+  if (lane == 0 && rows > 0) {
+    const int gw = (int)((env0 - env_begin) / kWave) & (kStampWaves - 1);
+    for (int i = 0; i < 12; ++i) salp_stamp_out[gw * 16 + i] = stamps.acc[i];
+  }
+#endif
 
   if (rows > 0 && active) {
     const DevParams& C = cold->P;
@@ -975,6 +1014,13 @@ void salp_vec_destroy(salp_vec_t* h) {
 int64_t salp_vec_num_envs(const salp_vec_t* h) { return h ? h->n : 0; }
 int salp_vec_obs_dim(const salp_vec_t* h) { return h ? h->obs_dim : 0; }
 int salp_vec_act_dim(const salp_vec_t* h) { return h ? h->act_dim : 0; }
+#ifdef SALP_EXP_STAMPS
+// experiment build only: the per-wavefront phase cycle sums of the last rollout launches (16 words per wavefront)
+int salp_exp_read_stamps(uint32_t* dst, int words) {
+  const size_t n = sizeof(uint32_t) * (size_t)(words < kStampWaves * 16 ? words : kStampWaves * 16);
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(salp_stamp_out), n, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 int salp_vec_num_food(const salp_vec_t* h) { return h ? h->F : 0; }
 int salp_vec_device(const salp_vec_t* h) { return h ? h->device : -1; }
 int64_t salp_vec_global_step(const salp_vec_t* h) { return h ? h->global_step : 0; }
