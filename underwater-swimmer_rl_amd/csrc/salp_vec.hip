@@ -287,8 +287,13 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       }
     } else {  // prefetch the next step's action (the last step re-reads its own: keeps the load unconditional)
       const int64_t nb = (rowbase + ((t + 1 < H) ? P.n : 0) + envc) * AD;
+#ifdef SALP_EXP_ACT_NT   // experiment: the action read as a streaming (non-temporal) load
+      a0 = __builtin_nontemporal_load(&io.act[nb]);
+      if (!FORCED) a1 = __builtin_nontemporal_load(&io.act[nb + 1]);
+#else
       a0 = io.act[nb];
       if (!FORCED) a1 = io.act[nb + 1];
+#endif
     }
 
 #ifdef SALP_EXP_STORE_ONLY   // experiment build: no simulation, only the output stream
