@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
 #endif
   constexpr int PITCH = SWZ ? 4 * QMAX : 4 * QMAX + 4;     // LDS row pitch in floats
   // Where the food positions of a multi-food env live: up to 12 slots in VGPRs (salp_food_reg.h: the pass
-  // leaves fp32 offsets in a small LDS block), above that in LDS (salp_food_lds.h); one food is plain registers.
+  // leaves each slot's (dx, dy) in a per-wavefront LDS block), above that in LDS (salp_food_lds.h); one food is plain registers.
 #ifdef SALP_EXP_LDS_FOOD      // experiment build: the LDS-resident form for every multi-food kernel
   constexpr bool REGF = false;
   constexpr bool LDSF = FMAX > 1;
