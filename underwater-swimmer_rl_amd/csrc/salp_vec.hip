@@ -333,6 +333,9 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
         asm volatile("global_store_byte %0, %1, off " SALP_EXP_SMALL_STORE_BITS :: "v"(&io.truncated[rowbase + env]), "v"(uv_) : "memory");
       } else
 #endif
+#ifdef SALP_EXP_LATE_SMALL_STORES   // experiment: reward / flags stored right AFTER the observation rows (FULL kernels)
+      if constexpr (!FULL)
+#endif
       {
       if (FULL || io.reward) io.reward[rowbase + env] = o.reward;
       if (FULL || io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
@@ -509,6 +512,15 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#ifdef SALP_EXP_LATE_SMALL_STORES
+    if constexpr (FULL) {
+      if (active) {
+        io.reward[rowbase + env] = o.reward;
+        io.terminated[rowbase + env] = o.terminated ? 1 : 0;
+        io.truncated[rowbase + env] = o.truncated ? 1 : 0;
+      }
+    }
+#endif
 #ifdef SALP_EXP_VMCNT
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SALP_EXP_VMCNT) : "memory");
 #elif !defined(SALP_EXP_NO_DRAIN)
