@@ -449,7 +449,7 @@ __device__ __forceinline__ int reset_pose(Env<FMAX>& e, const DevParams& P, uint
 // The seven increments of one thrust step, in the order legacy:261-314 applies them:
 //   vx = ((vx + t.ax) + t.bx) + t.cx,  vy likewise,  omega = omega + t.om
 // (main jet, side thrust, jitter).  A function of (theta, nozzle, water before this step's decay, r = max(a, b),
-// the env's draw counter and global index) only — so it can be evaluated by ANY lane (ThrustPool below).
+// the env's draw counter and global index) only.
 struct ThrustTerms { double ax, ay, bx, by, cx, cy, om; };
 template <bool STD>
 __device__ __forceinline__ ThrustTerms jet_thrust_terms(double th, double noz, double water, double r, uint32_t rng,
@@ -522,69 +522,10 @@ __device__ __forceinline__ void apply_jet_thrust(EnvCore& e, const DevParams& P,
   apply_thrust_terms(e, jet_thrust_terms<STD>(e.th, e.noz, e.water, r, e.rng, genv, P));
 }
 
-// ---- block-pooled thrust (experiment, -DSALP_EXP_POOL; measured slower, see salp_vec.hip) ---------------
-// The thrust block is ~200 VALU instructions and runs for a wavefront whenever ANY of its 64 lanes thrusts; the
-// breathing phases of the lanes are desynchronised by autoresets, so that is nearly every step, with ~22 % of the
-// lanes active (the exhale window is 61 of 273 steps).  The four wavefronts of a workgroup hold ~56 thrusting
-// lanes per step between them — one wavefront's worth.  With POOL the thrusting lanes of the whole workgroup
-// push their inputs into an LDS queue, ONE wavefront (rotating with the step number; a second one if more than 64
-// entries) evaluates jet_thrust_terms for all of them at full lane occupancy, and the owners read their seven
-// increments back and apply them in the reference's order: bit-identical results, a quarter of the thrust
-// instructions.  Cost: two workgroup barriers per step — every wavefront of the workgroup executes exactly two,
-// unconditionally, in every step of the loop (the host launches the pooled kernel on whole 256-env workgroups
-// only), so the barriers cannot deadlock.
-// Inputs and outputs are separate LDS regions, each single-buffered, and that is race-free: inputs are written
-// before barrier 1 of a step and read between its barriers 1 and 2 — a wavefront that writes the NEXT step's
-// inputs has passed barrier 2, i.e. the readers are done; outputs are written between the barriers and read by
-// their owners after barrier 2 — they are rewritten after barrier 1 of the next step, which every owner only
-// reaches after its reads.  (Outputs aliased onto the inputs would not be: a fast wavefront's next inputs could
-// overwrite outputs a slow owner has not read yet.)
-struct ThrustPool {
-  double* in;           // [4][256]: th, noz, water, r
-  double* out;          // [7][256]: the seven increments
-  uint2* meta;          // [256]: (draw counter, owner = wave * 64 + lane)
-  unsigned* count;      // [2]: entries of the current step (double-buffered by step parity)
-  uint64_t genv_block0; // global env index of the workgroup's first env
-  int wave, lane, t;
-};
-constexpr int kPoolN = 256;
-
-template <bool STD>
-__device__ __forceinline__ void pooled_thrust(EnvCore& e, const DevParams& P, const ThrustPool& q, bool thrust, double r) {
-  const int buf = q.t & 1;
-  const unsigned long long m = __ballot(thrust);
-  const unsigned cnt = (unsigned)__popcll(m);
-  unsigned base = 0;
-  if (q.lane == 0) base = atomicAdd(&q.count[buf], cnt);
-  base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-  const unsigned slot = base + (unsigned)__popcll(m & ((1ull << q.lane) - 1ull));
-  if (thrust) {
-    q.in[0 * kPoolN + slot] = e.th; q.in[1 * kPoolN + slot] = e.noz; q.in[2 * kPoolN + slot] = e.water; q.in[3 * kPoolN + slot] = r;
-    q.meta[slot] = make_uint2(e.rng, (unsigned)(q.wave * 64 + q.lane));
-  }
-  __syncthreads();                                   // barrier 1: every entry of the step is queued
-  const unsigned M = q.count[buf];
-  for (unsigned g = 0; g * 64u < M; ++g) {           // wave-uniform
-    if (((unsigned)q.t + g) % 4u == (unsigned)q.wave) {
-      const unsigned i = g * 64u + (unsigned)q.lane;
-      if (i < M) {
-        const uint2 mt = q.meta[i];
-        const ThrustTerms tt = jet_thrust_terms<STD>(q.in[0 * kPoolN + i], q.in[1 * kPoolN + i], q.in[2 * kPoolN + i],
-                                                     q.in[3 * kPoolN + i], mt.x, q.genv_block0 + (uint64_t)mt.y, P);
-        q.out[0 * kPoolN + i] = tt.ax; q.out[1 * kPoolN + i] = tt.ay; q.out[2 * kPoolN + i] = tt.bx; q.out[3 * kPoolN + i] = tt.by;
-        q.out[4 * kPoolN + i] = tt.cx; q.out[5 * kPoolN + i] = tt.cy; q.out[6 * kPoolN + i] = tt.om;
-      }
-    }
-  }
-  __syncthreads();                                   // barrier 2: every entry is answered
-  if (q.wave == 0 && q.lane == 0) q.count[buf] = 0u; // this buffer is pushed to again two steps from now
-  if (thrust) {
-    ThrustTerms tt;
-    tt.ax = q.out[0 * kPoolN + slot]; tt.ay = q.out[1 * kPoolN + slot]; tt.bx = q.out[2 * kPoolN + slot]; tt.by = q.out[3 * kPoolN + slot];
-    tt.cx = q.out[4 * kPoolN + slot]; tt.cy = q.out[5 * kPoolN + slot]; tt.om = q.out[6 * kPoolN + slot];
-    apply_thrust_terms(e, tt);
-  }
-}
+// (Two experiments that lived here are gone from the source, their measurements are in profiles/r02/ab_notes.md and
+// their code in the history: a block-pooled thrust — one wavefront evaluating the thrust of a workgroup's four
+// between two barriers, bit-identical and 35 % slower, session 6 — and the step's fp64 constants pinned in VGPRs —
+// -1.8 % at equal residency, +5 % once its 217 VGPRs cost the third wavefront per SIMD, session 3.)
 
 // Geometry of the nearest live food (first minimum, snake:350-364) in fp64 state terms.
 struct Nearest {
@@ -652,46 +593,6 @@ __device__ __forceinline__ float relative_heading(float dy, float dx, float th) 
   return rel;
 }
 
-// fp64 constants of the per-step path, held in VGPRs across the step loop (multi-food kernels).
-// gfx950 has no 64-bit literals: an fp64 constant operand is two s_mov_b32 (or two v_mov_b32 when it is
-// the addend of a v_fmac_f64) in front of its use, and a wavefront issues one instruction of any kind per
-// 4 cycles — in the 12-food kernel ~150 of ~1200 instructions per step were such moves outside the thrust
-// block.  The multi-food kernels are issue-bound at 2 wavefronts per SIMD and have the registers (<= 256):
-// their constants are made opaque once before the loop (vreg_const), which pins them in VGPR pairs that
-// VALU instructions read directly.  The one-food kernel (write-bound, 4 wavefronts per SIMD at <= 128 VGPRs)
-// keeps the literals: KV() resolves to CV() there at compile time.
-struct HotK {
-  double max_nozzle, nozzle_rate, inhale_d, a_rest, b_rest, da_inh, db_inh, ab_full, da_exh, db_exh;
-  double water_min, exhale_d, p3, p1, drag, ang_drag, pi, twopi, margin, W, H, k04, k07;
-  double wall_hi_x, wall_hi_y, food_radius, cap_slack;
-};
-__device__ __forceinline__ double vreg_const(double c) {
-  asm volatile("" : "+v"(c));
-  return c;
-}
-template <bool STD, bool HOIST>
-__device__ __forceinline__ HotK make_hotk(const DevParams& P) {
-  HotK k;
-  if constexpr (HOIST) {
-    k.max_nozzle = vreg_const(CV(max_nozzle)); k.nozzle_rate = vreg_const(CV(nozzle_rate));
-    k.inhale_d = vreg_const((double)CV(inhale_dur));
-    k.a_rest = vreg_const(CV(a_rest)); k.b_rest = vreg_const(CV(b_rest));
-    k.da_inh = vreg_const(CV(da_inh)); k.db_inh = vreg_const(CV(db_inh));
-    k.ab_full = vreg_const(CV(ab_full)); k.da_exh = vreg_const(CV(da_exh)); k.db_exh = vreg_const(CV(db_exh));
-    k.water_min = vreg_const(0.05); k.exhale_d = vreg_const(CV(exhale_dur_d)); k.p3 = vreg_const(0.3);
-    k.p1 = vreg_const(0.1);
-    k.drag = vreg_const(CV(drag)); k.ang_drag = vreg_const(CV(ang_drag));
-    k.pi = vreg_const(SALP_PI); k.twopi = vreg_const(SALP_2PI);
-    k.margin = vreg_const(CV(margin)); k.W = vreg_const(CV(W)); k.H = vreg_const(CV(H));
-    k.k04 = vreg_const(0.4); k.k07 = vreg_const(0.7);
-    k.wall_hi_x = vreg_const(CV(wall_hi_x)); k.wall_hi_y = vreg_const(CV(wall_hi_y));
-    k.food_radius = vreg_const(CV(food_radius)); k.cap_slack = vreg_const(1.00000000001);
-  }
-  return k;
-}
-// KV(field, literal-or-CV expression): the hoisted copy when HOIST, else the expression itself
-#define KV(field, expr) (HOIST ? hk.field : (expr))
-
 struct StepOut {
   double rmax;    // max(ellipse_a, ellipse_b) of this step
   float reward;
@@ -705,9 +606,8 @@ struct StepOut {
 // limit = 50) when o.collected && P.respawn, BEFORE any autoreset so the draw order of the
 // reference is kept.  (The all-collected termination test only applies when !P.respawn.)
 // legacy:119-156 up to and including the wall bounce; returns r = max(ellipse_a, ellipse_b) of this step.
-template <bool FORCED, bool STD, bool HOIST = false, bool POOL = false>
-__device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint64_t genv, float a0, float a1, const HotK& hk = HotK(),
-                                            const ThrustPool* pool = nullptr SALP_STAMP_PARAM) {
+template <bool FORCED, bool STD>
+__device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint64_t genv, float a0, float a1 SALP_STAMP_PARAM) {
   int phase = bw_phase(e.packed), timer = bw_timer(e.packed), dur = bw_dur(e.packed);
   // legacy:121-135
   double nd;
@@ -720,7 +620,7 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
     inhaling = a0 > 0.5f;
     nd = (double)a1;
   }
-  const double max_noz = KV(max_nozzle, CV(max_nozzle)), noz_rate = KV(nozzle_rate, CV(nozzle_rate));
+  const double max_noz = CV(max_nozzle), noz_rate = CV(nozzle_rate);
   const double target = nd * max_noz;
   // legacy:169-182 _update_nozzle
   {
@@ -737,7 +637,7 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
   double water_next = e.water;
   {
     const int tnew = timer + 1;
-    const double den = (phase == 2) ? (double)dur : KV(inhale_d, (double)CV(inhale_dur));
+    const double den = (phase == 2) ? (double)dur : (double)CV(inhale_dur);
     // p = tnew / den, correctly rounded, without the fp64 division sequence (~14 VALU incl. v_rcp_f64): with
     // y = RN(1 / den), q0 = RN(tnew y), r = tnew - den q0 (exact in an fma), RN(q0 + r y) is the IEEE quotient
     // (Markstein) — checked exhaustively for every den in 1..255 and tnew in 1..257.  y is a constant for the
@@ -751,8 +651,8 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
         if (odd) yden = 1.0 / (double)dur;
       }
     }
-    const double a_rest = KV(a_rest, CV(a_rest)), b_rest = KV(b_rest, CV(b_rest)), da_inh = KV(da_inh, CV(da_inh)), db_inh = KV(db_inh, CV(db_inh));
-    const double ab_full = KV(ab_full, CV(ab_full)), da_exh = KV(da_exh, CV(da_exh)), db_exh = KV(db_exh, CV(db_exh));
+    const double a_rest = CV(a_rest), b_rest = CV(b_rest), da_inh = CV(da_inh), db_inh = CV(db_inh);
+    const double ab_full = CV(ab_full), da_exh = CV(da_exh), db_exh = CV(db_exh);
 #ifdef SALP_EXP_IEEE_DIV
     const double p = (double)tnew / den;
 #else
@@ -770,9 +670,9 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
         water_next = p;
       } else {
         a = a_rest + da_inh * e.water; b = b_rest + db_inh * e.water;  // unchanged ellipse
-        if (e.water > KV(water_min, 0.05)) {
+        if (e.water > 0.05) {
           phase = 2; timer = 0;
-          dur = (int)(KV(exhale_d, CV(exhale_dur_d)) * pymax(e.water, KV(p3, 0.3)));
+          dur = (int)(CV(exhale_dur_d) * pymax(e.water, 0.3));
         } else {
           hold = (timer >= 1 && timer <= 6) ? timer : 0;
           phase = 0; timer = 0; water_next = 0.0;
@@ -782,7 +682,7 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
       if (p <= 1.0) {
         timer = tnew;
         a = ab_full + da_exh * p; b = ab_full + db_exh * p;
-        thrust = (KV(p1, 0.1) <= p) && (p <= 0.5);
+        thrust = (0.1 <= p) && (p <= 0.5);
         const double v = e.water * (1.0 - p);
         water_next = (v > 0) ? v : 0.0;
       } else {
@@ -796,18 +696,17 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
   thrust = false;
 #endif
   SALP_STAMP(1);
-  if constexpr (POOL) pooled_thrust<STD>(e, P, *pool, thrust, r);     // two workgroup barriers, executed by every lane
-  else if (thrust) apply_jet_thrust<1, STD>(e, P, genv, r);
+  if (thrust) apply_jet_thrust<1, STD>(e, P, genv, r);
   SALP_STAMP(2);
   e.water = water_next;
   e.packed = pack_breath(phase, timer, dur, hold);
   // legacy:316-352 _update_physics
-  e.vx = e.vx * KV(drag, CV(drag)); e.vy = e.vy * KV(drag, CV(drag)); e.om = e.om * KV(ang_drag, CV(ang_drag));
+  e.vx = e.vx * CV(drag); e.vy = e.vy * CV(drag); e.om = e.om * CV(ang_drag);
   e.x = e.x + e.vx; e.y = e.y + e.vy; e.th = e.th + e.om;
   // legacy:329-332 `while theta > pi: theta -= 2 pi` / `while theta < -pi: ...`.  |omega| is far below
   // 2 pi, so one conditional step each is the common case; the (bounded) loops only run if a lane
   // is still outside, e.g. after an injected state.
-  const double pi = KV(pi, SALP_PI), twopi = KV(twopi, SALP_2PI);
+  const double pi = SALP_PI, twopi = SALP_2PI;
   if (e.th > pi) e.th -= twopi;
   if (e.th < -pi) e.th += twopi;
   if (__any(e.th > pi || e.th < -pi)) {
@@ -817,9 +716,9 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
     for (int it = 0; it < 8 && e.th < -pi; ++it) e.th += twopi;
   }
   {
-    const double m = KV(margin, CV(margin)) + r;
-    const double hx = KV(W, CV(W)) - m, hy = KV(H, CV(H)) - m;
-    const double k04 = KV(k04, 0.4), k07 = KV(k07, 0.7);
+    const double m = CV(margin) + r;
+    const double hx = CV(W) - m, hy = CV(H) - m;
+    const double k04 = 0.4, k07 = 0.7;
     if (e.x < m) { e.x = m; e.vx = fabs(e.vx) * k04; e.om = e.om * k07; }
     else if (e.x > hx) { e.x = hx; e.vx = -fabs(e.vx) * k04; e.om = e.om * k07; }
     if (e.y < m) { e.y = m; e.vy = fabs(e.vy) * k04; e.om = e.om * k07; }

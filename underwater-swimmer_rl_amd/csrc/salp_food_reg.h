@@ -121,17 +121,17 @@ __device__ __forceinline__ void clear_slot(Env<FMAX>& e, bool doit, int k) {
 }
 
 // One reference step of a multi-food env (the register counterpart of step_env_lds).
-template <int FMAX, int KMAX, bool FORCED, bool STD, bool HOIST, bool POOL>
-__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& sc, const DevParams& P, const HotK& hk, uint64_t genv,
-                                                float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, const ThrustPool* pool,
+template <int FMAX, int KMAX, bool FORCED, bool STD>
+__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& sc, const DevParams& P, uint64_t genv,
+                                                float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive,
                                                 const DevParams* cold SALP_STAMP_PARAM) {
   // `cold`: the device-memory copy of the launch constants (ColdBlock).  The capture bonus and the collision
   // penalty are read from it inside the wave-uniform branches that need them (a few percent of the steps), so
   // their four fp64 constants and two predicate masks do not sit in — and get spilled from — scalar registers.
-  const double r = step_head<FORCED, STD, HOIST, POOL>(e, P, genv, a0, a1, hk, pool SALP_STAMP_PASS);
+  const double r = step_head<FORCED, STD>(e, P, genv, a0, a1 SALP_STAMP_PASS);
   StepOut o;
   o.rmax = r;
-  const double cr = r + KV(food_radius, CV(food_radius));
+  const double cr = r + CV(food_radius);
   const double cr2 = cr * cr;
   int hit_k, cnt_;
   bool all_live = (KMAX <= FMAX) && __all(nlive == FMAX);     // wave-uniform; then every lane also has K foods to show
@@ -139,7 +139,7 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& s
   else scan_foods_reg<FMAX, KMAX, false, false>(e, sc, P.F, 0.0, q, o.collected, hit_k, cnt_);
   SALP_STAMP(4);
   double rew = 0.0;                                              // snake:278-327, terms added in the reference's order
-  if (__any(q.key[0] < cr2 * KV(cap_slack, 1.00000000001))) {   // see step_env_lds
+  if (__any(q.key[0] < cr2 * 1.00000000001)) {   // see step_env_lds
     scan_foods_reg<FMAX, KMAX, true, true>(e, sc, P.F, cr2, q, o.collected, hit_k, nlive);
     clear_slot<FMAX>(e, o.collected, hit_k);
     all_live = false;
@@ -152,8 +152,8 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& s
   // instructions: 168 VGPRs + 21 spilled against 145)
   resolve_reg<KMAX>(sc, K > 0 ? K : 1, q);   // the reward needs the nearest even when K = 0
   {
-    const double mg = KV(margin, CV(margin));
-    o.collision = (e.x - r <= mg) || (e.x + r >= KV(wall_hi_x, CV(wall_hi_x))) || (e.y - r <= mg) || (e.y + r >= KV(wall_hi_y, CV(wall_hi_y)));
+    const double mg = CV(margin);
+    o.collision = (e.x - r <= mg) || (e.x + r >= CV(wall_hi_x)) || (e.y - r <= mg) || (e.y + r >= CV(wall_hi_y));
   }
   if (__any(o.collision)) {
     const double pen = cold->collision_penalty;

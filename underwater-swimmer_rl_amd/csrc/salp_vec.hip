@@ -39,9 +39,7 @@ constexpr int kWave = 64;
 #ifndef SALP_ALLFOUND_OBS
 #define SALP_ALLFOUND_OBS 1
 #endif
-#ifdef SALP_EXP_HOIST
-#define SALP_MULTI_WAVES 2
-#elif defined(SALP_EXP_WAVES4)
+#ifdef SALP_EXP_WAVES4
 #define SALP_MULTI_WAVES 4
 #else
 #define SALP_MULTI_WAVES 3     // multi-food kernels (<= 12 slots): <= 168 VGPRs, 3 wavefronts per SIMD
@@ -129,18 +127,6 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   // execute in order; a wavefront fence separates the two uses for the compiler.  12 slots: 12288 B per wavefront.
   constexpr int WAVE_FLOATS = (REGF && 4 * FMAX > PITCH) ? kWave * 4 * FMAX : kWave * PITCH;
   __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * WAVE_FLOATS];
-#ifdef SALP_EXP_POOL   // experiment build: block-pooled thrust (salp_device.h ThrustPool) in whole-workgroup launches of
-  // the register-food kernels.  Bit-identical results, a quarter of the thrust instructions — and 35 % SLOWER
-  // (2.85 against 2.12 ms, profiles/r02/ab_notes.md session 6): the two workgroup barriers per step put the four
-  // wavefronts in lockstep and three of them idle while the fourth evaluates the queue.  Not shipped.
-  constexpr bool POOL = REGF && !RAGGED && kBlock == 256;
-#else
-  constexpr bool POOL = false;
-#endif
-  __shared__ __attribute__((aligned(16))) double pool_in[POOL ? 4 * kPoolN : 1];
-  __shared__ __attribute__((aligned(16))) double pool_out[POOL ? 7 * kPoolN : 1];
-  __shared__ __attribute__((aligned(8))) uint2 pool_meta[POOL ? kPoolN : 1];
-  __shared__ unsigned pool_count[2];
   constexpr bool ALIAS_OFFS = REGF;
 
   const int tid = threadIdx.x;
@@ -202,10 +188,6 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   // accumulated with LDS integer atomics inside the rare-event branch instead of living in VGPRs.
   __shared__ unsigned long long blk_stats[16];
   if (tid < 16) blk_stats[tid] = 0ull;
-  if (tid < 2) pool_count[tid] = 0u;
-  if constexpr (POOL) {   // pooled kernels run on whole workgroups only (launch_rollout): a partial one does nothing
-    if (env_begin + ((int64_t)blockIdx.x + 1) * kBlock > env_end) return;   // uniform for the workgroup, before any barrier
-  }
   __syncthreads();
 
   using EnvT = std::conditional_t<LDSF, EnvCore, Env<FMAX>>;
@@ -243,14 +225,6 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   // path), and that wait drains the previous step's stores on every iteration.
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
-#ifdef SALP_EXP_HOIST   // experiment build: fp64 constants of the step pinned in VGPRs (salp_device.h HotK).
-  // Measured (profiles/r02/ab_notes.md session 3): -1.8 % at equal residency (~100 fewer s_mov / v_mov per
-  // step: scalar moves co-issue, they were nearly free) but 217 VGPRs cost the third wavefront per SIMD: +5 %.
-  constexpr bool kHoist = REGF && FMAX > 4;
-#else
-  constexpr bool kHoist = false;
-#endif
-  const HotK hotk = make_hotk<STD, kHoist>(P);
   const int Hrun = (rows > 0) ? H : 0;   // a wavefront past the end of the range runs zero steps
 #ifdef SALP_EXP_BLOCK_SYNC
   const bool block_full = env_begin + ((int64_t)blockIdx.x + 1) * kBlock <= env_end;
@@ -303,12 +277,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     StepOut o;
     if constexpr (LDSF) o = step_env_lds<KMAX, FORCED, STD>(e, food, P, genv, c0, c1, K, fq, nlive);
     else if constexpr (REGF) {
-      ThrustPool pool{pool_in, pool_out, pool_meta, pool_count, P.env_base + (uint64_t)(env_begin + (int64_t)blockIdx.x * kBlock), wave, lane, t};
 #ifdef SALP_EXP_STAMPS
       { StampAcc* stamps_ = &stamps; SALP_STAMP(0); }
-      o = step_env_reg<FMAX, KMAX, FORCED, STD, kHoist, POOL>(e, offs, P, hotk, genv, c0, c1, K, fq, nlive, &pool, &cold->P, &stamps);
+      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, offs, P, genv, c0, c1, K, fq, nlive, &cold->P, &stamps);
 #else
-      o = step_env_reg<FMAX, KMAX, FORCED, STD, kHoist, POOL>(e, offs, P, hotk, genv, c0, c1, K, fq, nlive, &pool, &cold->P);
+      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, offs, P, genv, c0, c1, K, fq, nlive, &cold->P);
 #endif
     }
     else o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
@@ -892,15 +865,8 @@ struct Bump {  // carve sub-buffers out of the staging allocation
 int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
   const bool full = io.obs && io.reward && io.terminated && io.truncated && !io.final_obs && !io.info;
   const bool gen = io.act == nullptr;               // only reached when can_generate_in_kernel()
-  // envs in full wavefronts: unpredicated kernel; the register-food kernels pool the thrust work of a workgroup
-  // (ThrustPool) and take whole 256-env workgroups
-#ifdef SALP_EXP_POOL
-  const bool pooled = h->kmax == 3 && h->std_consts && h->fmax > 1 && h->fmax <= 12;
-#else
-  const bool pooled = false;
-#endif
-  const int64_t gran = pooled ? kBlock : kWave;
-  int64_t n_full = h->n / gran * gran;
+  // envs in full wavefronts: unpredicated kernel
+  int64_t n_full = h->n / kWave * kWave;
   // A small ragged batch (step-per-launch acting loops) is launch-bound: one predicated launch over the whole
   // range instead of two; the predicates only cost when the write stream is the bound.
   if (n_full < h->n && h->n * (int64_t)H <= (int64_t)1 << 22) n_full = 0;
