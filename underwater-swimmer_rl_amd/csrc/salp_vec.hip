@@ -173,17 +173,6 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     asm volatile("" : "+v"(i));
     flush_src[j] = reinterpret_cast<const v4f*>(lds + i);
   }
-#ifdef SALP_EXP_PACKED_PLAN
-  uint32_t plan_pk[3] = {0u, 0u, 0u};
-  if constexpr (!RAGGED && QMAX == 6) {
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const uint32_t off = (uint32_t)((wave * WAVE_FLOATS + lds_off[j]) * 4);
-      plan_pk[j >> 1] |= off << (16 * (j & 1));
-    }
-    asm volatile("" : "+v"(plan_pk[0]), "+v"(plan_pk[1]), "+v"(plan_pk[2]));   // keep the packed form: do not re-derive the six
-  }
-#endif
   // Event statistics (episodes, terminations, food, ...) change on rare steps only: they are
   // accumulated with LDS integer atomics inside the rare-event branch instead of living in VGPRs.
   __shared__ unsigned long long blk_stats[16];
@@ -448,15 +437,6 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
 #endif
       {
         v4f tv[QMAX];
-#ifdef SALP_EXP_PACKED_PLAN   // experiment: the six flush offsets as three packed VGPRs (two 16-bit byte offsets each)
-        if constexpr (!RAGGED && QMAX == 6) {
-#pragma unroll
-          for (int j = 0; j < QMAX; ++j) {
-            const uint32_t off = (j & 1) ? (plan_pk[j >> 1] >> 16) : (plan_pk[j >> 1] & 0xFFFFu);
-            tv[j] = *reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(lds) + off);
-          }
-        } else
-#endif
 #pragma unroll
         for (int j = 0; j < QMAX; ++j)
           if (j < Q && (!RAGGED || lds_off[j] >= 0)) tv[j] = *flush_src[j];
