@@ -175,8 +175,14 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& s
 // of the env being served (lane L) are broadcast with v_readlane (slot index static, L wave-uniform), an
 // accepted point is written into lane L's slot through a wave-uniform switch.  Draws, order and stream
 // consumption are exactly those of the serial sampler (place_food in salp_device.h).
+// `scratch`: FMAX double2 of LDS private to the wavefront (the kernel lends the tile bytes, idle at this point of the
+// step).  An accepted point is wave-uniform and belongs in ONE lane's slot `slot` (wave-uniform as well): written as
+// `for k: if (slot == k) if (lane == L) fx[k] = ax` the compiler predicates all FMAX bodies — 97 instructions per
+// accepted food at 12 slots, ~1200 per reset — so the points of a batch go to the scratch (one LDS store each) and
+// lane L takes them into its registers once per batch (~8 instructions per filled slot).
 template <int FMAX, bool STD>
-__device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, int lane, const DevParams& P, uint64_t genv, int todo, int limit) {
+__device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, int lane, const DevParams& P, uint64_t genv, int todo, int limit,
+                                                    double2* scratch) {
   unsigned long long need = __ballot(todo > 0);
   const double min2 = CV(min_food_dist2);
   // empty slots of the own env as a bit mask (bit k: slot k < F is empty)
@@ -214,6 +220,7 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, int lane, cons
         }
       }
       int j = 0;                                   // first candidate of this batch not yet judged
+      uint32_t filled = 0u;                        // slots of env L that received a point in this batch
       while (todo_l > 0 && j < kFoodLanes) {
         const unsigned long long okm = __ballot(ok) & (~0ull << j);
         const int first_ok = okm ? (__ffsll((long long)okm) - 1) : kFoodLanes;
@@ -224,12 +231,8 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, int lane, cons
         if (empty) {                               // first empty slot (snake:120, 261-264)
           const int slot = __builtin_amdgcn_readfirstlane(__ffs((int)empty) - 1);
           empty &= empty - 1;
-#pragma unroll
-          for (int k = 0; k < FMAX; ++k) {
-            if (slot == k) {                       // wave-uniform
-              if (lane == L) { e.fx[k] = ax; e.fy[k] = ay; }
-            }
-          }
+          if (lane == 0) scratch[slot] = make_double2(ax, ay);
+          filled |= 1u << slot;
         }
         {
           const double dx = x - ax, dy = y - ay;
@@ -240,6 +243,21 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, int lane, cons
         j = a + 1;
       }
       consumed += (uint32_t)j;
+      if (filled) {                                // wave-uniform: lane L takes this batch's points (a later batch tests against them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < FMAX; ++k) {
+          if ((filled >> k) & 1u) {                // wave-uniform
+            const double2 v = scratch[k];          // same address in every lane: LDS broadcast
+            if (lane == L) { e.fx[k] = v.x; e.fy[k] = v.y; }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
     }
     if (lane == L) e.rng = rng0 + consumed;
   }

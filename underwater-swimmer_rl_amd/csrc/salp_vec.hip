@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 #endif
-        else if constexpr (REGF) place_food_coop_reg<FMAX, STD>(e, lane, C, genv, todo, limit);
+        else if constexpr (REGF) place_food_coop_reg<FMAX, STD>(e, lane, C, genv, todo, limit, reinterpret_cast<double2*>(tile));
         else place_food<FMAX, STD>(e, C, genv, todo, limit);
         todo = 0;
       }
