@@ -206,7 +206,18 @@ int salp_vec_get_state(salp_vec_t* h, double* f64, int32_t* i32, uint32_t flags,
 int salp_vec_set_state(salp_vec_t* h, const double* f64, const int32_t* i32, uint32_t flags,
                        void* stream);
 
-int salp_vec_get_stats(salp_vec_t* h, salp_stats_t* out);  /* synchronises the handle's work */
+/* Re-keys the draw streams and starts over: afterwards the handle is in exactly the state salp_vec_create(cfg, n, dev,
+ * seed, base) returns — new key words, every draw counter at 0, every env freshly reset (snake:133-155 `reset(seed)`,
+ * legacy:95-96), statistics and global step cleared; base_num_food_items keeps a value set by
+ * salp_vec_set_base_num_food.  Nothing is freed or reallocated and no launch parameter changes (the kernels read the
+ * key words from device memory), so device pointers stay valid and a hipGraph captured on this handle before the call
+ * replays correctly after it.  Asynchronous on `stream` with device pointers.  obs (may be NULL): float [n_envs][obs_dim],
+ * the first observations. */
+int salp_vec_reseed(salp_vec_t* h, uint64_t seed, float* obs, uint32_t flags, void* stream);
+
+/* Totals of everything issued so far: waits for the stream of the handle's most recent call (not for the device). */
+int salp_vec_get_stats(salp_vec_t* h, salp_stats_t* out);
+/* Stream-ordered behind the handle's most recent call; does not synchronise. */
 int salp_vec_clear_stats(salp_vec_t* h);
 int64_t salp_vec_global_step(const salp_vec_t* h);
 

@@ -20,7 +20,13 @@ Q = 6
 layouts = {'112-B padded pitch (round 1)': lambda r, c: r * 112 + 16 * c,
            '96-B pitch, no swizzle': lambda r, c: r * 96 + 16 * c,
            '96-B pitch, column ^ bit 2 of row (shipped)': lambda r, c: r * 96 + 16 * (c ^ ((r >> 2) & 1))}
-for name, f in layouts.items():
+SHIPPED = '96-B pitch, column ^ bit 2 of row (shipped)'
+def model(f):
+    """(LDS cycles of the six row writes, LDS cycles of the six flush reads) for layout f(row, column) -> byte offset."""
     w = sum(cycles(wr_groups(), lambda l, q=q: f(l, q), 32) for q in range(Q))
     rd = sum(cycles(rd_groups(), lambda l, j=j: f((j * 64 + l) // Q, (j * 64 + l) % Q), 64) for j in range(Q))
-    print(f'{name:46s} writes {w:3d} cycles (ideal {8 * Q})   flush reads {rd:3d} cycles (ideal {4 * Q})')
+    return w, rd
+if __name__ == '__main__':
+    for name, f in layouts.items():
+        w, rd = model(f)
+        print(f'{name:46s} writes {w:3d} cycles (ideal {8 * Q})   flush reads {rd:3d} cycles (ideal {4 * Q})')

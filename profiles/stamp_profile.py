@@ -44,11 +44,25 @@ def main():
     waves = min(n // 64, 8192)
     buf = np.zeros(waves * 16, np.uint32)
     assert lib.salp_exp_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.size) == 0
-    a = buf.reshape(waves, 16)[:, :12].astype(np.float64) / H          # cycles per step, per wavefront
+    raw = buf.reshape(waves, 16)
+    a = raw[:, :12].astype(np.float64) / H          # cycles per step, per wavefront
     tot = a.sum(1)
+    # wall clock of each wavefront's loop (s_memrealtime, 100 MHz): its clock = shader cycles / wall time; when it started
+    real = (raw[:, 13].astype(np.int64) - raw[:, 12].astype(np.int64)) & 0xFFFFFFFF
+    start = (raw[:, 12].astype(np.int64) - int(raw[:, 12].min())) & 0xFFFFFFFF
+    clock_ghz = raw[:, :12].astype(np.float64).sum(1) / np.maximum(real, 1) * 0.1
+    timing = {"wave_wall_us_mean": float(real.mean() / 100), "wave_wall_us_p10_p90": [float(np.percentile(real, 10) / 100), float(np.percentile(real, 90) / 100)],
+              "clock_ghz_mean": float(clock_ghz.mean()), "clock_ghz_p10_p90": [float(np.percentile(clock_ghz, 10)), float(np.percentile(clock_ghz, 90))],
+              "start_us_percentiles_50_75_90_100": [float(np.percentile(start, q) / 100) for q in (50, 75, 90, 100)],
+              "end_us_max": float(((start + real).max()) / 100)}
+    r1 = start < 0.5 * start.max() if start.max() > 20000 else np.ones_like(start, bool)    # first round: started early
+    pct = lambda v: [float(np.percentile(v, q) / 100) for q in (0, 10, 50, 90, 99, 100)] if v.size else []
+    timing["round1_waves"] = int(r1.sum()); timing["round1_wall_us_pct_0_10_50_90_99_100"] = pct(real[r1])
+    timing["round2_waves"] = int((~r1).sum()); timing["round2_wall_us_pct"] = pct(real[~r1]); timing["round2_start_us_pct"] = pct(start[~r1])
+    timing["round2_end_us_pct"] = pct((start + real)[~r1])
     out = {"preset": preset, "envs": n, "horizon": H, "kernel_ms_last_launch": ev[0].elapsed_time(ev[1]),
            "cycles_per_step_mean": float(tot.mean()), "cycles_per_step_p10_p90": [float(np.percentile(tot, 10)), float(np.percentile(tot, 90))],
-           "rare_event_steps_share": None,
+           "timing": timing,
            "phases": {PHASES[i]: {"cycles_per_step": float(a[:, i].mean()), "share": float(a[:, i].mean() / tot.mean())} for i in range(12)}}
     print(json.dumps(out, indent=1))
 

@@ -278,6 +278,59 @@ def main(only=None):
                   notes="done ignored: wall contacts and truncation without reset")
     assert ev["terminated"] >= 5 and ev["truncated"] >= 5
 
+    # --- tie order of the food sort (snake:382 `list.sort(key=distance)` is stable; :350-364 strict `<` keeps the first
+    #     minimum).  The swimmer rests at the tank centre for the first ~135 steps of forced breathing (no thrust before
+    #     exhale step 15), so the injected geometry holds for >100 observations, then it swims off along +x and the ties
+    #     resolve.  Five envs per fixture, the four "tie" foods in slots that are NOT in ascending order of insertion:
+    #       0: four foods at exactly distance 100            -> the three lowest slots, in slot order
+    #       1: the lowest tie slot 4 ulp farther (d2 + 6 ulp, inside a 16-ulp packed key) -> it is the FOURTH, not shown
+    #       2: d2 one ulp larger but sqrt(d2) == 150.0 == the others' (the sort key is the distance) -> still first
+    #       3: one food at 100.00001 (same float32 position as 100): indistinguishable in fp32, clearly fourth in fp64
+    #       4: 2e-9 apart in distance, well inside fp32 rounding, in the order opposite to the slots
+    #     with 4 foods (register path, 4 slots), 12 (the sac_gail kernel) and 16 (foods in LDS).
+    def tie_case(F, slots):
+        s0, s1, s2, s3 = slots
+
+        def inj(f64, i32):
+            n = f64.shape[1]
+            assert n == 5
+            f64[F_X], f64[F_Y] = 400.0, 300.0
+            f64[F_VX] = f64[F_VY] = f64[F_THETA] = f64[F_OMEGA] = 0.0
+            # the other foods: far away, all distinct
+            for k in range(F):
+                ang = 0.37 + 2.399963 * k
+                rad = 215.0 + 6.5 * k
+                f64[F_FOOD0 + k] = 400.0 + rad * math.cos(ang)
+                f64[F_FOOD0 + F + k] = 300.0 + 0.7 * rad * math.sin(ang)
+            def put(env, slot, x, y):
+                f64[F_FOOD0 + slot, env], f64[F_FOOD0 + F + slot, env] = x, y
+            for env in range(5):
+                d = 150.0 if env == 2 else 100.0
+                put(env, s0, 400.0 + d, 300.0); put(env, s1, 400.0 - d, 300.0)
+                put(env, s2, 400.0, 300.0 + d); put(env, s3, 400.0, 300.0 - d)
+            low = min(slots)     # the tie food that slot order would show first
+            lx = {s0: 1.0, s1: -1.0}.get(low, 0.0); ly = {s2: 1.0, s3: -1.0}.get(low, 0.0)
+            put(1, low, 400.0 + lx * (100.0 + 4 * 1.4210854715202004e-14), 300.0 + ly * (100.0 + 4 * 1.4210854715202004e-14))
+            put(2, low, 400.0 + lx * 150.0 + abs(ly) * 1.9e-6, 300.0 + ly * 150.0 + abs(lx) * 1.9e-6)
+            put(3, low, 400.0 + lx * 100.00001, 300.0 + ly * 100.00001)
+            hi = max(slots)
+            hx = {s0: 1.0, s1: -1.0}.get(hi, 0.0); hy = {s2: 1.0, s3: -1.0}.get(hi, 0.0)
+            put(4, hi, 400.0 + hx * (100.0 - 2e-9), 300.0 + hy * (100.0 - 2e-9))
+            # the properties the cases rely on, in the reference's own arithmetic
+            def d2(env, slot):
+                return (f64[F_FOOD0 + slot, env] - 400.0) ** 2 + (f64[F_FOOD0 + F + slot, env] - 300.0) ** 2
+            oth = [k for k in slots if k != low][0]
+            assert d2(0, s0) == d2(0, s1) == d2(0, s2) == d2(0, s3) == 10000.0
+            assert 0 < (d2(1, low) - 10000.0) / 1.8189894035458565e-12 < 16 and math.sqrt(d2(1, low)) > 100.0
+            assert d2(2, low) > d2(2, oth) == 22500.0 and math.sqrt(d2(2, low)) == 150.0
+            assert np.float32(f64[F_FOOD0 + low, 3]) == np.float32(f64[F_FOOD0 + low, 0]) and d2(3, low) > 10000.0
+            assert np.float32(d2(4, hi)) == np.float32(10000.0) and d2(4, hi) < 10000.0
+        return inj
+    for F, slots in ((4, (2, 1, 3, 0)), (12, (7, 2, 9, 4)), (16, (13, 5, 15, 8))):
+        run_case(f"tie_order_f{F}", dict(preset="sac_gail", num_food_items=F, proximity_reward_weight=2.0),
+                 np.zeros((220, 5, 1), np.float32), seed=40 + F, inject=tie_case(F, slots),
+                 notes="equal and nearly equal food distances: stable sort on sqrt(d2), first minimum for the reward")
+
     # --- env_index_base: the same global envs from a shard
     run_case("shard_base_1000", dict(preset="single_food_long_horizon"), uniform_actions(128, 4, 1, 23), seed=1001,
              base=1000, notes="global env indices 1000..1003")

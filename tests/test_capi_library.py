@@ -107,3 +107,53 @@ def test_headers_are_plain_c99(tmp_path):
                    "int main(void) { salp_config_t c; salp_robot_config_t r; salp_stats_t s; (void)c; (void)r; (void)s; return 0; }\n")
     subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
                     "-fsyntax-only", str(src)], check=True)
+
+
+def _build_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_salp_build", os.path.join(ROOT, "underwater-swimmer_rl_amd", "csrc", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def test_build_dependencies_cover_every_source_file(lib):
+    """The staleness check of csrc/build.py: every header / source the library is compiled from is a dependency (globbed),
+    and an edit to any ONE of them — content, not file time — makes the built library stale.  (Round 2 shipped a
+    hand-written list that missed salp_food_reg.h, and prebuilt .so files travel to the GPU box.)"""
+    import glob
+    import shutil
+    import tempfile
+    b = _build_module()
+    deps = b.deps()
+    csrc = os.path.join(ROOT, "underwater-swimmer_rl_amd", "csrc")
+    want = glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    assert sorted(os.path.realpath(d) for d in deps) == sorted(os.path.realpath(w) for w in want)
+    names = {os.path.basename(d) for d in deps}
+    assert {"salp_vec.hip", "salp_robot.hip", "salp_device.h", "salp_food_lds.h", "salp_food_reg.h", "salp_vec.h", "salp_robot.h"} <= names
+    assert b.is_current()                       # the fixture built it: the stored hash matches the tree
+    # touch every dependency in turn (in a scratch copy of the tree) and see the library go stale
+    with tempfile.TemporaryDirectory() as tmp:
+        copies = []
+        for d in deps:
+            c = os.path.join(tmp, os.path.basename(d))
+            shutil.copy(d, c)
+            copies.append(c)
+        real_deps, b.deps = b.deps, (lambda: sorted(copies))
+        try:
+            base = b.source_hash()
+            out = os.path.join(tmp, "lib.so")
+            open(out, "wb").close()
+            with open(out + ".hash", "w") as f:
+                f.write(base + "\n")
+            assert b.is_current(out)
+            for c in copies:
+                with open(c, "ab") as f:
+                    f.write(b"\n// touched\n")
+                assert b.source_hash() != base, c
+                assert not b.is_current(out), c     # build() would recompile
+                shutil.copy([d for d in deps if os.path.basename(d) == os.path.basename(c)][0], c)
+                assert b.is_current(out)
+            assert not b.is_current(out, defines=("SALP_EXP_STAMPS",))   # another variant is another library
+        finally:
+            b.deps = real_deps

@@ -1,0 +1,57 @@
+"""Checks behind two claims the kernel source makes without the compiler being able to prove them.
+
+(a) csrc/salp_device.h step_head(): `p = timer / duration` of the breathing cycle (legacy:212-213, :240-246) is computed as
+    y = RN(1/den), q0 = RN(t y), p = RN(q0 + RN_fma(t - den q0) y) instead of the IEEE division sequence, and is claimed
+    to equal the correctly rounded quotient for every duration 1..255 and timer 1..257.  Checked here in exact rationals.
+(b) csrc/salp_vec.hip: the observation tile (96-B rows, float4 column XOR bit 2 of the row) is claimed conflict-free for
+    both the row writes (ds_write_b128) and the flush reads (ds_read_b128) under the banking table of
+    MI355X_MICROARCH.md §LDS; profiles/isa_lds_model.py is that table as code.
+"""
+import importlib.util
+import os
+from fractions import Fraction
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rn(x: Fraction) -> float:
+    """Round-to-nearest-even of an exact rational to binary64 (CPython's int / int is correctly rounded)."""
+    return x.numerator / x.denominator
+
+
+def test_reciprocal_fma_quotient_is_the_ieee_quotient():
+    bad = []
+    for den in range(1, 256):
+        y = 1.0 / den                                    # RN(1 / den): IEEE division
+        fy, fden = Fraction(y), Fraction(den)
+        for t in range(1, 258):
+            ft = Fraction(t)
+            q0 = rn(ft * fy)                              # v_mul_f64
+            r = rn(ft - fden * Fraction(q0))              # v_fma_f64(-den, q0, t)
+            p = rn(Fraction(q0) + Fraction(r) * fy)       # v_fma_f64(r, y, q0)
+            if p != t / den:
+                bad.append((den, t, p, t / den))
+    assert not bad, bad[:5]
+
+
+def test_the_thrust_window_of_forced_breathing_is_an_integer_test():
+    """0.1 <= t/150 <= 0.5 exactly for t = 15..75 (61 steps), evaluated on the rounded quotient."""
+    on = [t for t in range(1, 152) if 0.1 <= t / 150 <= 0.5]
+    assert on == list(range(15, 76))
+
+
+def test_swizzled_observation_tile_is_conflict_free():
+    spec = importlib.util.spec_from_file_location("isa_lds_model", os.path.join(ROOT, "profiles", "isa_lds_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    w, rd = m.model(m.layouts[m.SHIPPED])
+    assert (w, rd) == (8 * m.Q, 4 * m.Q)                 # one LDS cycle per lane group: no conflict anywhere
+    w1, rd1 = m.model(m.layouts['112-B padded pitch (round 1)'])
+    assert w1 == 8 * m.Q and rd1 == 2 * 4 * m.Q          # round 1: writes clean, flush reads 2-way (63.5 M conflict cycles measured)
+    # the kernel's own formulas (salp_vec.hip: lds_off, myrow_even / myrow_odd) are this layout
+    f = m.layouts[m.SHIPPED]
+    for lane in range(64):
+        swz = (lane >> 2) & 1
+        for q in range(6):
+            mine = lane * 96 + 16 * ((q - swz) if (q & 1) else (q + swz))
+            assert mine == f(lane, q)

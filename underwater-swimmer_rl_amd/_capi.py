@@ -28,6 +28,7 @@ EXPORTS = (
     "salp_vec_num_food", "salp_vec_device", "salp_vec_reset", "salp_vec_step", "salp_vec_rollout",
     "salp_vec_observe", "salp_vec_get_state", "salp_vec_set_state", "salp_vec_get_stats",
     "salp_vec_clear_stats", "salp_vec_global_step", "salp_vec_set_base_num_food", "salp_vec_base_num_food",
+    "salp_vec_reseed",
 )
 
 
@@ -87,6 +88,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.salp_vec_set_state.argtypes = [vp, vp, vp, u32, vp]
     L.salp_vec_get_stats.argtypes = [vp, ctypes.POINTER(CStats)]
     L.salp_vec_clear_stats.argtypes = [vp]
+    if path is None or hasattr(L, "salp_vec_reseed"):   # (an explicit path may be an older A/B variant, profiles/ab_bench.py)
+        L.salp_vec_reseed.argtypes = [vp, u64, vp, u32, vp]
     L.salp_vec_global_step.argtypes = [vp]
     L.salp_vec_global_step.restype = i64
     L.salp_vec_set_base_num_food.argtypes = [vp, i32]
@@ -158,6 +161,11 @@ class SalpLib:
                                                   self._ptr(reward), self._ptr(term), self._ptr(trunc),
                                                   self._ptr(final_obs), self._ptr(act_out), flags,
                                                   ctypes.c_void_p(stream)), "salp_vec_rollout")
+
+    def reseed(self, seed, obs, flags, stream=0):
+        """New draw streams keyed by `seed`, every env reset from draw counter 0; no reallocation (capture-safe)."""
+        check(self.lib, self.lib.salp_vec_reseed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, self._ptr(obs), flags,
+                                                 ctypes.c_void_p(stream)), "salp_vec_reseed")
 
     def observe(self, obs, flags, stream=0):
         check(self.lib, self.lib.salp_vec_observe(self._h, self._ptr(obs), flags, ctypes.c_void_p(stream)),

@@ -9,9 +9,17 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "salp_vec.hip")             # SalpSnakeEnv.step hot path
 SRC_ROBOT = os.path.join(HERE, "salp_robot.hip")     # HEAD Robot simulator
-DEPS = [SRC, SRC_ROBOT, os.path.join(HERE, "salp_device.h"), os.path.join(HERE, "salp_food_lds.h"),
-        os.path.join(HERE, "..", "..", "include", "salp_vec.h"),
-        os.path.join(HERE, "..", "..", "include", "salp_robot.h")]
+INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
+
+
+def deps() -> list:
+    """Every file the library is compiled from: all of csrc/*.h, csrc/*.hip and include/*.h (globbed, so that a new
+    header cannot be forgotten — round 2 shipped a list that missed salp_food_reg.h)."""
+    import glob
+    return sorted(glob.glob(os.path.join(HERE, "*.h")) + glob.glob(os.path.join(HERE, "*.hip")) +
+                  glob.glob(os.path.join(INCLUDE, "*.h")))
+
+
 OUT = os.path.join(HERE, "libsalp_hip.so")
 # -ffp-contract=off: the fp64 state update must round exactly where the reference rounds
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -31,10 +39,34 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+def source_hash(defines=(), extra_flags=()) -> str:
+    """sha256 over the contents of every dependency, the compiler flags and the defines: what the built library is a
+    function of.  Stored next to the library (`<out>.hash`); a library whose stored hash differs is stale whatever the
+    file times say (prebuilt .so files travel to the GPU box with the snapshot, where mtimes mean nothing)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in deps():
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(repr((FLAGS, sorted((os.path.basename(k), v) for k, v in SRC_FLAGS.items()), list(defines), list(extra_flags))).encode())
+    return h.hexdigest()
+
+
+def is_current(out: str = OUT, defines=(), extra_flags=()) -> bool:
+    try:
+        with open(out + ".hash") as f:
+            return os.path.isfile(out) and f.read().strip() == source_hash(defines, extra_flags)
+    except OSError:
+        return False
+
+
 def build(force: bool = False, verbose: bool = False, out: str = OUT, defines=(), extra_flags=()) -> str:
     """`out`/`defines`/`extra_flags` build experiment variants (profiles/ab_bench.py); the product is the default."""
-    if not force and os.path.isfile(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+    if not force and is_current(out, defines, extra_flags):
         return out
+    digest = source_hash(defines, extra_flags)
     objs, procs = [], []
     for src in (SRC, SRC_ROBOT):      # one compile per source (different flags), in parallel, then link
         obj = out + "." + os.path.splitext(os.path.basename(src))[0] + ".o"
@@ -52,6 +84,8 @@ def build(force: bool = False, verbose: bool = False, out: str = OUT, defines=()
     subprocess.run(link, check=True, cwd=HERE)
     for o in objs:
         os.remove(o)
+    with open(out + ".hash", "w") as f:
+        f.write(digest + "\n")
     return out
 
 

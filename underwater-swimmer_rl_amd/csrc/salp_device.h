@@ -34,6 +34,13 @@ struct StampAcc { uint32_t last; uint32_t acc[12]; };
 #define SALP_STAMP(i) do {} while (0)
 #endif
 
+#ifdef SALP_EXP_COUNT     // experiment build: event counters (never in the product)
+__device__ unsigned long long salp_exp_counter[8];
+#define SALP_COUNT(i, cond) do { if (cond) { if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicAdd(&salp_exp_counter[i], 1ull); } } while (0)
+#else
+#define SALP_COUNT(i, cond) do {} while (0)
+#endif
+
 // ---- packed breathing word: phase[1:0] | timer[9:2] | exhale_dur[17:10] | shape_hold[20:18]
 __host__ __device__ inline uint32_t pack_breath(int phase, int timer, int dur, int hold) {
   return (uint32_t)(phase & 3) | ((uint32_t)(timer & 255) << 2) | ((uint32_t)(dur & 255) << 10) |
@@ -43,6 +50,11 @@ __host__ __device__ inline int bw_phase(uint32_t w) { return (int)(w & 3u); }
 __host__ __device__ inline int bw_timer(uint32_t w) { return (int)((w >> 2) & 255u); }
 __host__ __device__ inline int bw_dur(uint32_t w) { return (int)((w >> 10) & 255u); }
 __host__ __device__ inline int bw_hold(uint32_t w) { return (int)((w >> 18) & 7u); }
+
+// The key words of the draw streams are read through the constant address space: scalar loads (s_load_dwordx2, scalar
+// cache) wherever a kernel draws, no vector-memory wait.  They only change between launches (salp_vec_reseed), and the
+// scalar cache is invalidated at every kernel start.
+typedef const uint32_t __attribute__((address_space(4))) seed_word_t;
 
 // Constants derived on the host in fp64 exactly as the reference derives them.
 struct DevParams {
@@ -63,12 +75,15 @@ struct DevParams {
   // fp32 reciprocals for the observation
   double inv_W, inv_H, inv_pi, inv_R, inv_max_nozzle;
   float inv_diag;           // 1/sqrt(W^2+H^2)
+  float tie_c0;             // constant term of the fp32 food keys' error bound, 1.4e-7 max(W, H)^2 (salp_food_reg.h)
   int inhale_dur, exhale_dur, cycle_len, max_steps_wo_food;
   int F, K;                 // food slots (num_food_items at creation), max_observed_food
   int F_base;               // base_num_food_items: foods of the next episodes, 0..F (snake:36, :144-148)
   int forced, random_food_count, respawn;
   int autoreset;            // 0: finished envs keep running (salp_config_t.no_autoreset)
-  uint32_t seed_lo, seed_hi;
+  seed_word_t* seed;        // the two key words of the draw streams, in DEVICE memory (the handle's ColdBlock): a kernel
+                            // reads them where it draws, so salp_vec_reseed() changes them without changing any launch
+                            // parameter — a hipGraph captured before a reseed replays with the new key
   uint64_t env_base;        // global index of local env 0
   int64_t n;                // envs in this handle
   int64_t pitch;            // row pitch (elements) of the SoA state blocks
@@ -89,6 +104,7 @@ struct StdConsts {
   static constexpr double inv_W = 1.0 / 800.0, inv_H = 1.0 / 600.0, inv_pi = 1.0 / 3.141592653589793;
   static constexpr double inv_R = 1.0 / 30.0, inv_max_nozzle = 1.0 / 1.0471975511965976;
   static constexpr float inv_diag = 1.0e-3f;
+  static constexpr float tie_c0 = 0.0896f;
   static constexpr int inhale_dur = 120, exhale_dur = 150, cycle_len = 330;
 };
 // CV(name): the constant `name` for this instantiation
@@ -209,7 +225,7 @@ __device__ __forceinline__ U4 next_block(EnvCore& e, const DevParams& P, uint64_
   // The key is made opaque here: otherwise the 18 round keys (seed + r * Weyl constant) are hoisted out of the
   // step loop as loop invariants, spilled to VGPR lanes and read back with v_readlane on every use — two
   // scalar adds per round in place are cheaper.
-  uint32_t k0 = P.seed_lo, k1 = P.seed_hi;
+  uint32_t k0 = P.seed[0], k1 = P.seed[1];
   asm volatile("" : "+s"(k0), "+s"(k1));
   U4 w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), e.rng, 0u, k0, k1);
   e.rng += 1u;
@@ -482,7 +498,7 @@ __device__ __forceinline__ ThrustTerms jet_thrust_terms(double th, double noz, d
     t.by = mul_s(ss * S, TT[TT_K008]);
   }
   {  // jitter at fl(phi + d), d = fl((u - 0.5) * 0.05); one Philox block of the env's draw stream (counter rng)
-    uint32_t k0 = P.seed_lo, k1 = P.seed_hi, g0 = (uint32_t)genv;
+    uint32_t k0 = P.seed[0], k1 = P.seed[1], g0 = (uint32_t)genv;
     asm volatile("" : "+s"(k0), "+s"(k1));    // see next_block
     asm volatile("" : "+v"(g0));              // likewise the first-round product 0xD2511F53 * env_lo: one v_mad_u64_u32 here
                                               // instead of a 64-bit VGPR pair held across the step loop
@@ -653,13 +669,9 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
     }
     const double a_rest = CV(a_rest), b_rest = CV(b_rest), da_inh = CV(da_inh), db_inh = CV(db_inh);
     const double ab_full = CV(ab_full), da_exh = CV(da_exh), db_exh = CV(db_exh);
-#ifdef SALP_EXP_IEEE_DIV
-    const double p = (double)tnew / den;
-#else
     const double tn = (double)tnew;
     const double q0 = tn * yden;
-    const double p = fma(fma(-den, q0, tn), yden, q0);
-#endif
+    const double p = fma(fma(-den, q0, tn), yden, q0);   // == (double)tnew / den, tests/test_source_claims.py
     if (phase == 0) {
       a = a_rest; b = b_rest;
       if (inhaling) { phase = 1; timer = 0; }
@@ -871,19 +883,20 @@ __device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, 
 #pragma unroll
   for (int k = 0; k < FMAX; ++k) if ((left >> k) & 1u) dsum += d[k];
   } else {
-  // squared distances of live foods in fp64 (the sort key); offsets and distances in fp32 (the
-  // outputs).  Written with selects, not branches: with 12 foods the branchy form spent most of its
-  // time in exec-mask bookkeeping (−24 % on the sac_gail preset).
+  // (reset / observe kernels only: the rollout kernels select through salp_food_reg.h / salp_food_lds.h.)  The sort key
+  // is the reference's: the fp64 distance sqrt(dx^2 + dy^2) (snake:378-382; squared distances an ulp apart can share a
+  // distance, and then slot order decides); offsets and distances of the outputs in fp32.  Written with selects.
   double d2[FMAX];
   float d[FMAX], dxf[FMAX], dyf[FMAX];
   uint32_t live = 0;
 #pragma unroll
   for (int k = 0; k < FMAX; ++k) {
     const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
-    d2[k] = dx * dx + dy * dy;
+    const double sq = dx * dx + dy * dy;
+    d2[k] = __builtin_sqrt(sq);
     const bool ok = !is_none(e.fx[k]);
     dxf[k] = (float)dx; dyf[k] = (float)dy;
-    d[k] = __builtin_amdgcn_sqrtf((float)d2[k]);
+    d[k] = __builtin_amdgcn_sqrtf((float)sq);
     live |= ok ? (1u << k) : 0u;
     cnt += ok ? 1 : 0;
   }

@@ -28,17 +28,23 @@ struct FoodLds {
 
 // Result of one pass over the slots.
 //
-// Sort keys.  The K nearest are kept by a sorted insertion on PACKED keys: the fp64 squared distance with the
-// low 4 bits of its mantissa replaced by the slot number (slots are 0..15).  All keys of an env are then
-// distinct, so the compare-exchange of a chain stage is just v_min_f64 / v_max_f64 (no index selects), a
-// smaller key is a nearer food, and squared distances that agree to within 16 ulp of fp64 — which includes
-// exact ties — order by slot, like the reference's stable sort on sqrt(d2) (snake:382), which itself cannot
-// tell squared distances ~2 ulp apart.  An empty slot's key is kDeadKey | slot (finite, above any distance).
+// Sort keys (this file: more than 12 slots; up to 12 slots: fp32 keys, salp_food_reg.h).  The K nearest are kept by a
+// sorted insertion on PACKED keys: the fp64 squared distance with the low 4 bits of its mantissa replaced by the slot
+// number (slots are 0..15).  All keys of an env are then distinct, so the compare-exchange of a chain stage is just
+// v_min_f64 / v_max_f64 (no index selects) and a smaller key is a nearer food.  The reference orders by sqrt(d2) with a
+// stable sort (snake:382): squared distances a few ulp apart can collapse to one distance (then slot order), while
+// others inside the 16 ulp of the packing stay distinct (then distance order).  The pass therefore also keeps the
+// (K + 1)-th smallest key, and when two consecutive ones of any lane are closer than 2^-44 relative the wavefront
+// runs exact_order_lds() — the reference's own key — so the order is the reference's in every case
+// (tests/golden/ref_tie_order_f16.npz).  An empty slot's key is kDeadKey | slot (finite, above any distance).
 // Everything that leaves the selection (offsets, distance) is recomputed from the slot's exact position.
 template <int KMAX>
 struct FoodScan {
-  double key[KMAX];  // packed keys of the K nearest live foods, ascending
-  int idx[KMAX];     // their slots (-1: none)                                  (filled by resolve())
+  double key[KMAX];  // packed keys of the K nearest live foods, ascending               (LDS-food kernels)
+  double next;       // the (KMAX + 1)-th smallest packed key                             (LDS-food kernels)
+  uint32_t top[KMAX + 1];   // fp32 keys of the K + 1 nearest, ascending                  (register-food kernels)
+  bool tie;          // this lane's key order is inside its error bound: the exact order decides
+  int idx[KMAX];     // slots of the K nearest, nearest first (-1: none)
   float bx[KMAX], by[KMAX], bd[KMAX];   // offsets and distance of those foods in fp32  (filled by resolve())
   float dsum;        // sum of distances over ALL live foods
 };
@@ -84,6 +90,7 @@ __device__ __forceinline__ void scan_foods(const FoodLds& f, int F, double x, do
   const double dead = dead_key();
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) q.key[s] = dead;
+  double next = dead;
   float dsum = 0.f;
   int n = 0;
   collected = false;
@@ -111,13 +118,50 @@ __device__ __forceinline__ void scan_foods(const FoodLds& f, int F, double x, do
 #pragma unroll
       for (int s = 0; s < KMAX; ++s) {
         const double lo = min_key(cv, q.key[s]);
-        if (s + 1 < KMAX) cv = max_key(cv, q.key[s]);
+        cv = max_key(cv, q.key[s]);
         q.key[s] = lo;
       }
+      next = min_key(next, cv);      // what leaves the list: the smallest of those is the (KMAX + 1)-th key
     }
   }
   q.dsum = dsum;
+  q.next = next;
   if (COUNT) cnt = n;
+  // near ties among the KMAX + 1 smallest (see FoodScan); a pair whose larger key is an empty slot's is no tie
+  bool tie = false;
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    const double hi = (s + 1 < KMAX) ? q.key[s + 1] : next;
+    tie = tie || (key_found(hi) && (hi - q.key[s] < hi * 5.6843418860808015e-14));   // 2^-44
+    q.idx[s] = key_found(q.key[s]) ? key_slot(q.key[s]) : -1;
+  }
+  q.tie = tie;
+}
+
+// The reference's order, exactly (see exact_order_reg in salp_food_reg.h): distance = sqrt(dx^2 + dy^2) in fp64, K times
+// the first minimum among the foods not yet taken.  Rolled loops over the LDS slots: rare path, small code.
+template <int KMAX>
+__device__ __forceinline__ void exact_order_lds(const FoodLds& f, int F, int K, double x, double y, FoodScan<KMAX>& q) {
+  uint32_t taken = 0u;
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    int bk = -1;
+    if (s < K) {
+      double best = __builtin_inf();
+#pragma unroll 1
+      for (int k = 0; k < F; ++k) {
+        double fx, fy;
+        f.get(k, fx, fy);
+        const double dx = fx - x, dy = fy - y;
+        const double d = __builtin_sqrt(dx * dx + dy * dy);          // NaN for an empty slot
+        const bool take = !((taken >> k) & 1u) && (d < best);        // NaN never; ties keep the lower slot
+        best = take ? d : best;
+        bk = take ? k : bk;
+      }
+      taken |= (bk >= 0) ? (1u << bk) : 0u;
+    }
+    q.idx[s] = bk;
+  }
 }
 
 // fp32 geometry of the first K selected foods (what the reward and the observation consume), from the exact
@@ -126,14 +170,14 @@ template <int KMAX>
 __device__ __forceinline__ void resolve(const FoodLds& f, int K, double x, double y, FoodScan<KMAX>& q) {
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) {
-    q.bx[s] = 0.f; q.by[s] = 0.f; q.bd[s] = 0.f; q.idx[s] = -1;
+    q.bx[s] = 0.f; q.by[s] = 0.f; q.bd[s] = 0.f;
+    if (s >= K) q.idx[s] = -1;
     if (s < K) {
       double fx, fy;
-      const int k = key_slot(q.key[s]);
+      const bool found = q.idx[s] >= 0;
+      const int k = q.idx[s] & 15;
       f.get(k, fx, fy);
-      const bool found = key_found(q.key[s]);
       const double dx = fx - x, dy = fy - y;
-      q.idx[s] = found ? k : -1;
       q.bx[s] = found ? (float)dx : 0.f;
       q.by[s] = found ? (float)dy : 0.f;
       q.bd[s] = found ? __builtin_amdgcn_sqrtf((float)(dx * dx + dy * dy)) : 0.f;
@@ -160,6 +204,7 @@ __device__ __forceinline__ StepOut step_env_lds(EnvCore& e, const FoodLds& f, co
     scan_foods<KMAX, true, true>(f, P.F, e.x, e.y, cr2, q, o.collected, hit_k, nlive);
     if (o.collected) f.clear(hit_k);
   }
+  if (__any(q.tie)) exact_order_lds<KMAX>(f, P.F, K > 0 ? K : 1, e.x, e.y, q);
   resolve<KMAX>(f, K > 0 ? K : 1, e.x, e.y, q);   // the reward needs the nearest even when K = 0
   o.collision = (e.x - r <= CV(margin)) || (e.x + r >= CV(wall_hi_x)) || (e.y - r <= CV(margin)) || (e.y + r >= CV(wall_hi_y));
   double rew = 0.0;
@@ -224,43 +269,9 @@ __device__ __forceinline__ void observe_lds(const EnvCore& e, const DevParams& P
   }
 }
 
-// place_food (salp_device.h) on LDS slots: the same rejection sampler, draw for draw.
-template <bool STD>
-__device__ __forceinline__ void place_food_lds(EnvCore& e, const FoodLds& f, const DevParams& P, uint64_t genv, int todo, int limit) {
-  int attempts = 0;
-#pragma unroll 1
-  while (__any(todo > 0)) {
-    if (todo > 0) {
-      double x, y;
-      draw_xy<1, STD>(e, P, genv, x, y);
-      bool valid = true;
-      {
-        const double dx = x - e.x, dy = y - e.y;
-        if (dx * dx + dy * dy < CV(min_food_dist2)) valid = false;
-      }
-      int first_empty = -1;
-#pragma unroll 1
-      for (int k = 0; k < P.F; ++k) {
-        double fx, fy;
-        f.get(k, fx, fy);
-        const double dx = x - fx, dy = y - fy;
-        if (dx * dx + dy * dy < CV(min_food_dist2)) valid = false;   // NaN (empty) slots never reject
-        if (first_empty < 0 && is_none(fx)) first_empty = k;
-      }
-      if (valid || attempts >= limit) {
-        if (first_empty >= 0) f.set(first_empty, x, y);
-        todo -= 1;
-        attempts = 0;
-      } else {
-        attempts += 1;
-      }
-    }
-  }
-}
-
 // ---- wavefront-cooperative placement ---------------------------------------------------------------------
-// place_food_lds run by 64 lanes for the one or two envs of a wavefront that need food costs the whole
-// wavefront a serial rejection loop: an autoreset with 12 foods is ~18 draws, each a Philox block plus 12
+// The serial rejection sampler (place_food in salp_device.h) run by 64 lanes for the one or two envs of a wavefront
+// that need food costs the whole wavefront a serial rejection loop: an autoreset with 12 foods is ~18 draws, each a Philox block plus 12
 // distance tests, ~5000 instructions with 63 lanes idle, and with ~1/800 resets per env-step some lane of
 // a wavefront resets on ~8 % of the steps (measured: 37 % of the sac_gail kernel time).
 // Here the 64 lanes work for one env at a time: lane l draws candidate number (consumed + l) of THAT env's
@@ -268,7 +279,7 @@ __device__ __forceinline__ void place_food_lds(EnvCore& e, const FoodLds& f, con
 // reads), and the sequential acceptance rule of the reference — first valid draw, or the draw after
 // `limit` consecutive rejections — becomes a ballot / find-first per accepted food, with the later
 // candidates re-tested against each newly accepted one.  The draws taken, their order and the number
-// consumed from the env's stream are exactly those of place_food_lds.
+// consumed from the env's stream are exactly those of place_food.
 // value of `v` in lane `src` (src wave-uniform): two v_readlane instead of two LDS permutes
 __device__ __forceinline__ double bcast_lane(double v, int src) {
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -299,7 +310,7 @@ __device__ __forceinline__ void place_food_coop(EnvCore& e, double2* wave_block,
     int attempts = 0;
     while (todo_l > 0) {
       // 64 candidates: draw number consumed + lane
-      const U4 w = philox4x32_10(g_lo, g_hi, rng0 + consumed + (uint32_t)lane, 0u, P.seed_lo, P.seed_hi);
+      const U4 w = philox4x32_10(g_lo, g_hi, rng0 + consumed + (uint32_t)lane, 0u, P.seed[0], P.seed[1]);
       const double x = CV(food_xlo) + CV(food_xspan) * u53(w.x, w.y);
       const double y = CV(food_ylo) + CV(food_yspan) * u53(w.z, w.w);
       bool ok;

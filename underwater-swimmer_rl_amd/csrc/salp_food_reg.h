@@ -1,129 +1,333 @@
 // salp_food_reg.h — the multi-food side of the rollout kernel for up to 12 food slots (the presets: 5 in
-// defaults.yaml, 12 in sac_gail.yaml), with the food positions of an env in VGPRs.
+// defaults.yaml, 12 in sac_gail.yaml): food positions of an env in VGPRs (fp64, authoritative) with an fp32
+// mirror in LDS that everything which only LEAVES the simulator is computed from.
 //
-// The LDS-resident form (salp_food_lds.h, still used above 12 slots and by the generic instantiation) costs
-// 16 B x slots x 64 lanes of LDS per wavefront for the whole launch: with 12 slots 12 KB next to the 6 KB
-// observation tile, which caps the CU at 8 wavefronts (2 per SIMD), and the kernel is issue-bound with the VALU
-// ~58 % busy at that residency.  Since the step loop no longer keeps ~45 VGPRs of hoisted constants (build.py: no
-// machine LICM) the 48 VGPRs of 12 positions fit under the 168-VGPR budget of 3 wavefronts per SIMD.  What
-// registers cannot do is per-lane dynamic indexing — the K selected foods are only known as slot numbers after
-// the pass — so the pass leaves each slot's offset (dx, dy) in a per-wavefront LDS block that lives only from the
-// pass to the selection and shares its bytes with the observation tile (salp_vec.hip), written once per slot and
-// step, read K times.  The offsets are stored as the fp64 pair the pass has in registers (one ds_write_b128,
-// 12 KB per wavefront = 48 KB per workgroup, three workgroups per CU) and narrowed to fp32 for the K selected
-// slots only: storing fp32 pairs took two v_cvt_f32_f64 per slot and step, 24 of the kernel's ~680 VALU
-// instructions per wavefront-step, for values of which 3 are read (profiles/r02/ab_notes.md session 15).
-// The arithmetic on each food is the reference's, in its order, exactly as in salp_food_lds.h.
+// What feeds back into the state stays exact and in the reference's operation order: the capture test
+// (snake:204-217) and the placement tests (snake:92-131, 232-276) read the fp64 positions in registers.  What only
+// orders foods and fills float32 outputs — the K nearest (snake:366-382), their offsets / distances / bearings
+// (:386-410), the distance sum (:414-420), the reward's nearest food (:350-364) — runs in fp32 on the mirror:
+//   * one pass per step over the slots: (dx, dy) = mirror - (float)(x, y), d2 = fma(dy, dy, dx dx), sqrt for the
+//     distance sum, key = d2's bit pattern with the slot number in its low 4 bits.  fp32 add / mul / fma issue at 2.5
+//     cycles per wavefront on gfx950 where every fp64 (and most other) VALU instruction takes 4.3
+//     (profiles/micro/valu_rates2.hip): 45 against 59-63 cycles per slot for the round-2 fp64 pass, measured.
+//   * K = 3 (every preset): the three smallest keys AND the fourth through a sort-by-threes / merge network on
+//     v_min3 / v_med3 / v_max3_u32 — 37 instructions for 12 slots against 51 for the sorted insertion (which
+//     had no fourth key).  Positive floats order as unsigned integers, a NaN (empty slot) above every number.
+//   * exactness: the fp32 keys can mis-order two foods only if their squared distances are closer than the error
+//     bound of the fp32 evaluation (tie_tolerance below).  When a gap between two of the four smallest keys of any
+//     lane is inside that bound — ~1 % of the wavefront-steps with 12 foods — the wavefront runs exact_order_reg():
+//     the reference's own key, sqrt(dx^2 + dy^2) in fp64 from the fp64 positions, first minimum first (the stable
+//     sort of snake:382; strict `<` of :350-364).  The order is therefore the reference's in every case, exact ties and
+//     squared distances a few ulp apart included (tests/golden/ref_tie_order_f*.npz) — round 2's packed fp64 keys
+//     ordered foods within 16 ulp of each other by slot.
+//   * registers cannot be indexed per lane, and the K selected foods are only known as slot numbers after the pass:
+//     their positions are read back from the mirror (three ds_read_b64) — the round-2 kernel stored every slot's
+//     fp64 offset pair each step (twelve ds_write_b128) for the same purpose.
+// The mirror is written where the food set changes (kernel entry, capture, placement, reset): rare.
 #pragma once
 #include "salp_food_lds.h"
 
 namespace salp {
 
-struct OffsetLds {
-  double2* col;   // this lane's column of the wavefront's [FMAX][64] block of (dx, dy)
+struct MirrorLds {
+  float2* col;   // this lane's column of the wavefront's [FMAX][64] block of (x, y)
+  __device__ __forceinline__ float2 get(int k) const { return col[k * kFoodLanes]; }
+  __device__ __forceinline__ void set(int k, double x, double y) const { col[k * kFoodLanes] = make_float2((float)x, (float)y); }
+  __device__ __forceinline__ void clear(int k) const { col[k * kFoodLanes] = make_float2(__builtin_nanf(""), __builtin_nanf("")); }
 };
 
-// One pass over the slots (see scan_foods in salp_food_lds.h for CAPTURE / COUNT).  Groups of four slots
-// beyond F are skipped (wave-uniform); slots F..FMAX-1 inside a processed group are empty (NaN).
-// ALLLIVE: every slot 0..FMAX-1 of every lane holds a food (the common state with respawn: a captured food is
-// replaced in the same step) — no NaN can occur, so the two NaN guards of a slot (max(., 0) of the distance,
-// min(., dead) of the key) are dropped: 17 instead of 19 VALU per slot.
-template <int FMAX, int KMAX, bool CAPTURE, bool COUNT, bool ALLLIVE = false>
-__device__ __forceinline__ void scan_foods_reg(const Env<FMAX>& e, const OffsetLds& sc, int F, double cr2, FoodScan<KMAX>& q,
-                                               bool& collected, int& hit_k, int& cnt) {
-  const double dead = dead_key();
+// What the per-step pass reads (static slot index).  INREG (the K = 3 kernels): the mirror's values also in registers —
+// the pass then issues no LDS read at all (with six ds_read2st64_b64 and their waits in the pass the kernel ran 8 % slower
+// than round 2's, profiles/r03/ab_notes.md).  !INREG (the generic instantiation, already at its register limit): the pass
+// reads the mirror.
+template <int FMAX, bool INREG>
+struct FoodF32 {
+  float x[INREG ? FMAX : 1], y[INREG ? FMAX : 1];
+  __device__ __forceinline__ void set(int k, double fx, double fy) { if (INREG) { x[k] = (float)fx; y[k] = (float)fy; } }
+  __device__ __forceinline__ void clear(int k, bool doit) {
+    if (INREG) { x[k] = doit ? __builtin_nanf("") : x[k]; y[k] = doit ? __builtin_nanf("") : y[k]; }
+  }
+  __device__ __forceinline__ float2 get(int k, const MirrorLds& m) const { return INREG ? make_float2(x[k], y[k]) : m.get(k); }
+};
+
+// ---- unsigned min / max as instructions (the three-operand forms have no builtin)
+__device__ __forceinline__ uint32_t umin2(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax2(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r; asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+
+constexpr uint32_t kKeyNone = 0xFFFFFFFFu;     // above every key, NaN keys included
+constexpr uint32_t kKeyInf = 0x7F800000u;      // keys below this are live foods
+// key of slot k: the bit pattern of its squared distance (sign cleared: positive floats order as unsigned integers,
+// +inf and NaN above every finite value) with the slot number in the low 4 bits — all keys of an env are distinct
+__device__ __forceinline__ uint32_t key_of(float d2, int k) { return (__float_as_uint(d2) & 0x7FFFFFF0u) | (uint32_t)k; }
+
+// Error bound of the fp32 keys, as a gap in squared distance below which two keys may be in the wrong order.
+// Positions and pose are rounded to fp32 (half an ulp of a coordinate <= L = max(width, height): L 2^-25 each), the
+// difference once more, so |delta dx| <= e = 1.8e-7 L; d2 carries 2 sqrt2 d e from that plus two fp32 roundings
+// (1.2e-7 d2) plus the 4 slot bits (1.9e-6 d2): per key <= 2.83 e d + 2.1e-6 d2, per pair twice that.  With
+// tol(d2) = c0 + 8e-6 d2 the pair bound 5.66 e d + 4.2e-6 d2 <= tol needs c0 >= (5.66 e)^2 / (4 * 3.8e-6) = 6.9e-8 L^2;
+// c0 = 1.4e-7 L^2 (0.09 at L = 800; DevParams::tie_c0) keeps a factor two in hand.
+#ifdef SALP_EXP_TIE_OFF   // experiment: the tie test and the exact order compiled in, never taken
+__device__ __forceinline__ float tie_tolerance(float d2_max, float c0) { return fmaf(d2_max, 0.0f, -1.0f); }
+#else
+__device__ __forceinline__ float tie_tolerance(float d2_max, float c0) { return fmaf(d2_max, 8.0e-6f, c0); }
+#endif
+
+// ---- K = 3: sort-by-threes and merge, keeping the fourth smallest
+struct Tri { uint32_t a, b, c; };   // ascending
+__device__ __forceinline__ Tri sort3(uint32_t x, uint32_t y, uint32_t z) { return Tri{umin3(x, y, z), umed3(x, y, z), umax3(x, y, z)}; }
+// the three smallest of two sorted triples, and their fourth smallest into d
+__device__ __forceinline__ Tri merge33(const Tri& p, const Tri& q, uint32_t& d) {
+  const uint32_t t = umax2(p.a, q.a);
+  Tri r;
+  r.a = umin2(p.a, q.a);
+  r.b = umin3(t, p.b, q.b);
+  r.c = umin3(umed3(t, p.b, q.b), p.c, q.c);
+  d = umax3(t, umin2(p.b, q.c), umin2(p.c, q.b));     // third LARGEST of the six
+  return r;
+}
+__device__ __forceinline__ Tri merge32(const Tri& p, uint32_t qa, uint32_t qb, uint32_t& d) {   // q = (qa <= qb, none)
+  const uint32_t t = umax2(p.a, qa);
+  Tri r;
+  r.a = umin2(p.a, qa);
+  r.b = umin3(t, p.b, qb);
+  r.c = umin2(umed3(t, p.b, qb), p.c);
+  d = umax3(t, p.b, umin2(p.c, qb));
+  return r;
+}
+__device__ __forceinline__ Tri merge31(const Tri& p, uint32_t x, uint32_t& d) {                 // q = (x, none, none)
+  const uint32_t t = umax2(p.a, x), u = umax2(p.b, t);
+  Tri r;
+  r.a = umin2(p.a, x);
+  r.b = umin2(p.b, t);
+  r.c = umin2(p.c, u);
+  d = umax2(p.c, u);
+  return r;
+}
+
+// Smallest KMAX + 1 keys, ascending, of key[0..FMAX-1] into top[0..KMAX].
+template <int FMAX, int KMAX>
+__device__ __forceinline__ void select_keys(const uint32_t (&key)[FMAX], uint32_t (&top)[KMAX + 1]) {
+  if constexpr (KMAX == 3 && FMAX >= 3) {
+    Tri acc = sort3(key[0], key[1], key[2]);
+    uint32_t fourth = kKeyNone;
 #pragma unroll
-  for (int s = 0; s < KMAX; ++s) q.key[s] = dead;
-  float dsum = 0.f;
-  int n = 0;
-  collected = false;
-  hit_k = 0;
+    for (int g = 3; g < FMAX; g += 3) {
+      uint32_t d;
+      if (g + 2 < FMAX) acc = merge33(acc, sort3(key[g], key[g + 1], key[g + 2 < FMAX ? g + 2 : 0]), d);
+      else if (g + 1 < FMAX) acc = merge32(acc, umin2(key[g], key[g + 1 < FMAX ? g + 1 : 0]), umax2(key[g], key[g + 1 < FMAX ? g + 1 : 0]), d);
+      else acc = merge31(acc, key[g], d);
+      fourth = umin2(fourth, d);
+    }
+    top[0] = acc.a; top[1] = acc.b; top[2] = acc.c; top[3] = fourth;
+  } else {     // generic K: sorted insertion (slot k among min(k, KMAX + 1) entries)
 #pragma unroll
-  for (int k0 = 0; k0 < FMAX; k0 += 4) {
-    if (k0 == 0 || k0 < F) {   // the first group always runs (its slots beyond F are empty): it fills the list
+    for (int s = 0; s <= KMAX; ++s) top[s] = kKeyNone;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = k0 + j;
-        if (k < FMAX) {
-          const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
-          // CAPTURE (the pass that decides a capture, snake:204-217): the reference's two products and their sum.
-          // Otherwise the value only orders the foods (to 16 ulp, see the packed keys) and feeds fp32 outputs:
-          // one product folded into an fma (<= 1 ulp from the reference's value, one VALU instruction fewer).
-          double d2 = CAPTURE ? (dx * dx + dy * dy) : fma(dy, dy, dx * dx);   // NaN for an empty slot
-          if (CAPTURE) {
-            const bool hit = !collected && (d2 < cr2);   // NaN never hits
-            collected = collected || hit;
-            hit_k = hit ? k : hit_k;
-            d2 = hit ? __builtin_nan("") : d2;
-          }
-          if (COUNT) n += (d2 == d2) ? 1 : 0;
-          if (ALLLIVE) dsum += __builtin_amdgcn_sqrtf((float)d2);
-          else dsum += __builtin_fmaxf(__builtin_amdgcn_sqrtf((float)d2), 0.f);   // maxnum: NaN (empty) adds 0
-          sc.col[k * kFoodLanes] = make_double2(dx, dy);
-          double cv = pack_key(ALLLIVE ? d2 : min_key_s(d2, dead), k);
-          if (k < KMAX) {
-            // slots 0..KMAX-1 fill the list: entries k.. are still empty (= larger than any key), so slot k is
-            // inserted among k entries — 0, 2, 4 min/max instead of 5 each for K = 3
+    for (int k = 0; k < FMAX; ++k) {
+      uint32_t cv = key[k];
 #pragma unroll
-            for (int s = 0; s < KMAX; ++s) {
-              if (s < k) {
-                const double lo = min_key(cv, q.key[s]);
-                cv = max_key(cv, q.key[s]);
-                q.key[s] = lo;
-              }
-            }
-            q.key[k < KMAX ? k : 0] = cv;
-          } else {
-#pragma unroll
-            for (int s = 0; s < KMAX; ++s) {
-              const double lo = min_key(cv, q.key[s]);
-              if (s + 1 < KMAX) cv = max_key(cv, q.key[s]);
-              q.key[s] = lo;
-            }
-          }
+      for (int s = 0; s <= KMAX; ++s) {
+        if (s < k) {
+          const uint32_t lo = umin2(cv, top[s]);
+          if (s < KMAX) cv = umax2(cv, top[s]);
+          top[s] = lo;
         }
       }
+      if (k <= KMAX) top[k] = cv;
     }
+  }
+}
+
+// One fp32 pass over the slots around (xf, yf): distance sum, live count (COUNT), the K nearest as slot numbers in
+// q.idx (-1: none) and whether the fp32 order of this lane is inside its error bound (q.tie: then exact_order_reg decides).
+// ALLLIVE: every slot of every lane holds a food (the steady state with respawn): no NaN can occur, the NaN guard of
+// the distance sum and the found tests are dropped.
+template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT>
+__device__ __forceinline__ void scan_foods_f32(const FoodF32<FMAX, KMAX == 3>& ff, const MirrorLds& m, int K, float xf, float yf, float tol_c0,
+                                               FoodScan<KMAX>& q, int& cnt) {
+  uint32_t key[FMAX];
+  float dsum = 0.f;
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) {
+    const float2 p = ff.get(k, m);
+    const float dx = p.x - xf, dy = p.y - yf;
+    const float d2 = fmaf(dy, dy, dx * dx);          // NaN for an empty slot
+    if (COUNT) n += (d2 == d2) ? 1 : 0;
+    const float sq = __builtin_amdgcn_sqrtf(d2);
+    dsum += ALLLIVE ? sq : __builtin_fmaxf(sq, 0.f);   // maxnum: NaN (empty) adds 0
+    key[k] = key_of(d2, k);
   }
   q.dsum = dsum;
   if (COUNT) cnt = n;
-}
-
-// fp32 geometry of the first K selected foods: the offsets the pass left in LDS, narrowed here (the reference's
-// float32 cast of the fp64 difference), the distance from the key (the squared distance to within 16 ulp of fp64:
-// the same float except on ~3e-8 of the values, then 1 ulp).
-template <int KMAX>
-__device__ __forceinline__ void resolve_reg(const OffsetLds& sc, int K, FoodScan<KMAX>& q) {
+  select_keys<FMAX, KMAX>(key, q.top);
+  // gaps between consecutive keys of the K + 1 smallest against the error bound at the largest of them
+  float gap = 3.0e38f, top_d2 = 0.f;
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) {
-    q.bx[s] = 0.f; q.by[s] = 0.f; q.bd[s] = 0.f; q.idx[s] = -1;
     if (s < K) {
-      const int k = key_slot(q.key[s]);
-      const bool found = key_found(q.key[s]);
-      const double2 o = sc.col[k * kFoodLanes];
-      q.idx[s] = found ? k : -1;
-      q.bx[s] = found ? (float)o.x : 0.f;
-      q.by[s] = found ? (float)o.y : 0.f;
-      q.bd[s] = found ? __builtin_amdgcn_sqrtf((float)q.key[s]) : 0.f;
+      const float lo = __uint_as_float(q.top[s]), hi = __uint_as_float(q.top[s + 1]);
+      gap = __builtin_fminf(gap, hi - lo);                // a NaN key (none) gives a NaN gap: ignored by minnum
+      top_d2 = ALLLIVE ? hi : __builtin_fmaxf(top_d2, __builtin_fmaxf(lo, hi));
+    }
+  }
+  q.tie = gap < tie_tolerance(top_d2, tol_c0);
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    const bool found = ALLLIVE || (q.top[s] < kKeyInf);
+    q.idx[s] = (s < K && found) ? (int)(q.top[s] & 15u) : -1;
+  }
+}
+
+// The reference's order, exactly: the sort key is distance = sqrt(dx^2 + dy^2) in fp64 from the fp64 positions
+// (snake:378-379), and the K nearest are K times the first minimum among the foods not yet taken — what a stable sort by
+// distance (snake:382) and the strict `<` scan of snake:350-364 produce.  Runs for the whole wavefront when some lane's
+// fp32 order is inside its error bound.
+// Careful form: the distances themselves (the device's fp64 sqrt is correctly rounded) through a [FMAX][64] block of
+// doubles private to the wavefront (`dist`: this lane's column; the kernel lends the observation tile's bytes, idle in
+// the middle of a step), rolled selection loops.  Only reached when two squared distances are within 4 ulp (see below).
+template <int FMAX, int KMAX>
+__device__ __forceinline__ void exact_order_sqrt_reg(const Env<FMAX>& e, double* dist, int K, FoodScan<KMAX>& q) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch bytes have other users (tile rows, placement)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) {
+    const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
+    dist[k * kFoodLanes] = __builtin_sqrt(dx * dx + dy * dy);     // NaN for an empty slot
+  }
+  uint32_t taken = 0u;
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    int bk = -1;
+    if (s < K) {
+      double best = __builtin_inf();
+#pragma unroll 1
+      for (int k = 0; k < FMAX; ++k) {
+        const double d = dist[k * kFoodLanes];
+        const bool take = !((taken >> k) & 1u) && (d < best);      // NaN never; ties keep the lower slot
+        best = take ? d : best;
+        bk = take ? k : bk;
+      }
+      taken |= (bk >= 0) ? (1u << bk) : 0u;
+    }
+    q.idx[s] = bk;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Usual form: ONE pass of packed fp64 keys — the reference's squared distance dx^2 + dy^2 with the slot number in its low
+// 4 mantissa bits, sorted insertion on v_min_f64 / v_max_f64 (round 2's per-step pass, ~13 instructions per slot).  sqrt
+// is monotonic and squared distances more than 16 + 4 ulp apart keep their order through the packing and have different
+// (correctly rounded) square roots, so this IS the order of the distances unless two of the K + 1 smallest keys are closer
+// than 2^-44 relative — then, and only then, the careful form decides (squared distances 1 ulp apart can share a distance:
+// the tie goes to the lower slot; tests/golden/ref_tie_order_f*.npz envs 1 and 2).  It has to be cheap, not just rare:
+// a swimmer rests for the first ~135 steps of an episode, so a near tie at reset recurs on every one of them, and the
+// launch ends with its slowest wavefront (with three 36-slot rounds here the 12-food kernel lost 12 %, ab_notes.md).
+template <int FMAX, int KMAX>
+__device__ __forceinline__ void exact_order_reg(const Env<FMAX>& e, double* dist, int K, FoodScan<KMAX>& q) {
+  const double dead = dead_key();
+  double key[KMAX + 1];
+#pragma unroll
+  for (int s = 0; s <= KMAX; ++s) key[s] = dead;
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) {
+    double ex = e.x, ey = e.y;
+    asm volatile("" : "+v"(ex), "+v"(ey));     // one slot after the other: short live ranges (this path runs at the kernel's register limit)
+    const double dx = e.fx[k] - ex, dy = e.fy[k] - ey;
+    double cv = pack_key(min_key_s(dx * dx + dy * dy, dead), k);     // NaN (empty slot) -> the dead key
+#pragma unroll
+    for (int s = 0; s <= KMAX; ++s) {
+      if (s < k) {                                                     // slot k is inserted among min(k, KMAX + 1) entries
+        const double lo = min_key(cv, key[s]);
+        if (s < KMAX) cv = max_key(cv, key[s]);
+        key[s] = lo;
+      }
+    }
+    if (k <= KMAX) key[k] = cv;
+  }
+  bool close = false;
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    close = close || (s < K && key_found(key[s + 1]) && (key[s + 1] - key[s] < key[s + 1] * 5.6843418860808015e-14));   // 2^-44
+    q.idx[s] = (s < K && key_found(key[s])) ? key_slot(key[s]) : -1;
+  }
+  if (__any(close)) exact_order_sqrt_reg<FMAX, KMAX>(e, dist, K, q);
+}
+
+// fp32 geometry of the K selected foods from their mirror positions (the same differences the pass formed).
+template <int KMAX, bool ALLFOUND>
+__device__ __forceinline__ void resolve_f32(const MirrorLds& m, int K, float xf, float yf, FoodScan<KMAX>& q) {
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {
+    q.bx[s] = 0.f; q.by[s] = 0.f; q.bd[s] = 0.f;
+    if (s < K) {
+      const bool found = ALLFOUND || (q.idx[s] >= 0);
+      const float2 p = m.get(ALLFOUND ? q.idx[s] : (q.idx[s] & 15));
+      const float bx = p.x - xf, by = p.y - yf;
+      const float bd = __builtin_amdgcn_sqrtf(fmaf(by, by, bx * bx));
+      q.bx[s] = found ? bx : 0.f;
+      q.by[s] = found ? by : 0.f;
+      q.bd[s] = found ? bd : 0.f;
     }
   }
 }
 
-// slot `k` (per-lane) := empty, for the lanes with `doit`
+// Selection of the current food set around the current pose: pass, exact order where needed, geometry.
+// `dist`: see exact_order_reg.
+template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT>
+__device__ __forceinline__ void select_foods_reg(const Env<FMAX>& e, const FoodF32<FMAX, KMAX == 3>& ff, const MirrorLds& m, double* dist, int K,
+                                                 float tol_c0, FoodScan<KMAX>& q, int& cnt) {
+  const float xf = (float)e.x, yf = (float)e.y;
+  scan_foods_f32<FMAX, KMAX, ALLLIVE, COUNT>(ff, m, K, xf, yf, tol_c0, q, cnt);
+  if (__any(q.tie)) exact_order_reg<FMAX, KMAX>(e, dist, K, q);
+  resolve_f32<KMAX, ALLLIVE>(m, K, xf, yf, q);
+}
+
+// snake:204-217 _check_food_collection on the fp64 positions, in the reference's arithmetic: the first live food
+// inside the capture radius; also the number of foods alive afterwards.
 template <int FMAX>
-__device__ __forceinline__ void clear_slot(Env<FMAX>& e, bool doit, int k) {
+__device__ __forceinline__ void capture_test_reg(const Env<FMAX>& e, double cr2, bool& collected, int& hit_k, int& alive) {
+  collected = false;
+  hit_k = 0;
+  int n = 0;
+#pragma unroll
+  for (int k = 0; k < FMAX; ++k) {
+    const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
+    const double d2 = dx * dx + dy * dy;           // NaN for an empty slot
+    const bool hit = !collected && (d2 < cr2);     // NaN never hits
+    collected = collected || hit;
+    hit_k = hit ? k : hit_k;
+    n += (d2 == d2 && !hit) ? 1 : 0;
+  }
+  alive = n;
+}
+
+// slot `k` (per-lane) := empty, for the lanes with `doit`: registers (fp64 and fp32) and mirror
+template <int FMAX, bool INREG>
+__device__ __forceinline__ void clear_slot(Env<FMAX>& e, FoodF32<FMAX, INREG>& ff, const MirrorLds& m, bool doit, int k) {
 #pragma unroll
   for (int j = 0; j < FMAX; ++j) {
-    const bool m = doit && (k == j);
-    e.fx[j] = m ? __builtin_nan("") : e.fx[j];
-    e.fy[j] = m ? __builtin_nan("") : e.fy[j];
+    const bool hit = doit && (k == j);
+    e.fx[j] = hit ? __builtin_nan("") : e.fx[j];
+    e.fy[j] = hit ? __builtin_nan("") : e.fy[j];
+    ff.clear(j, hit);
   }
+  if (doit) m.clear(k);
 }
 
 // One reference step of a multi-food env (the register counterpart of step_env_lds).
 template <int FMAX, int KMAX, bool FORCED, bool STD>
-__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& sc, const DevParams& P, uint64_t genv,
-                                                float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive,
+__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, KMAX == 3>& ff, const MirrorLds& m, double* dist, const DevParams& P, uint64_t genv,
+                                                float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, int& order_cache,
                                                 const DevParams* cold SALP_STAMP_PARAM) {
   // `cold`: the device-memory copy of the launch constants (ColdBlock).  The capture bonus and the collision
   // penalty are read from it inside the wave-uniform branches that need them (a few percent of the steps), so
@@ -131,26 +335,62 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& s
   const double r = step_head<FORCED, STD>(e, P, genv, a0, a1 SALP_STAMP_PASS);
   StepOut o;
   o.rmax = r;
+  o.collected = false;
   const double cr = r + CV(food_radius);
-  const double cr2 = cr * cr;
-  int hit_k, cnt_;
+  const int Ksel = K > 0 ? K : 1;                // the reward needs the nearest even when K = 0
+  const float xf = (float)e.x, yf = (float)e.y;
+  const float tol_c0 = CV(tie_c0);
+  int cnt_;
   bool all_live = (KMAX <= FMAX) && __all(nlive == FMAX);     // wave-uniform; then every lane also has K foods to show
-  if (all_live) scan_foods_reg<FMAX, KMAX, false, false, true>(e, sc, P.F, 0.0, q, o.collected, hit_k, cnt_);
-  else scan_foods_reg<FMAX, KMAX, false, false>(e, sc, P.F, 0.0, q, o.collected, hit_k, cnt_);
+  if (all_live) scan_foods_f32<FMAX, KMAX, true, false>(ff, m, Ksel, xf, yf, tol_c0, q, cnt_);
+  else scan_foods_f32<FMAX, KMAX, false, false>(ff, m, Ksel, xf, yf, tol_c0, q, cnt_);
   SALP_STAMP(4);
   double rew = 0.0;                                              // snake:278-327, terms added in the reference's order
-  if (__any(q.key[0] < cr2 * 1.00000000001)) {   // see step_env_lds
-    scan_foods_reg<FMAX, KMAX, true, true>(e, sc, P.F, cr2, q, o.collected, hit_k, nlive);
-    clear_slot<FMAX>(e, o.collected, hit_k);
-    all_live = false;
-    const DevParams& C = *cold;
-    double bonus = C.food_reward;
-    if (C.efficiency_bonus > 0) bonus += C.efficiency_bonus * (double)(C.max_steps_wo_food - e.ssf);
-    rew = o.collected ? bonus : 0.0;
+  // A capture needs a live food with d2 < cr^2; its fp32 key is then below cr^2 plus the key's error bound (2.83 e d +
+  // 2.1e-6 d2 at d = cr <= ~60: < 0.02 + 1e-5 cr^2).  Only then — a few percent of the wavefront-steps — run the exact test.
+  {
+    const float crf = (float)cr;
+    if (__any(__uint_as_float(q.top[0]) < fmaf(crf * crf, 1.00002f, 0.05f + tol_c0))) {
+      int hit_k;
+      capture_test_reg<FMAX>(e, cr * cr, o.collected, hit_k, nlive);
+      if (__any(o.collected)) {
+        clear_slot(e, ff, m, o.collected, hit_k);
+        all_live = false;
+        // the reward's nearest food and the observation are taken after the slot is cleared (snake:171-189, 301)
+        scan_foods_f32<FMAX, KMAX, false, false>(ff, m, Ksel, xf, yf, tol_c0, q, cnt_);
+        const DevParams& C = *cold;
+        double bonus = C.food_reward;
+        if (C.efficiency_bonus > 0) bonus += C.efficiency_bonus * (double)(C.max_steps_wo_food - e.ssf);
+        rew = o.collected ? bonus : 0.0;
+      }
+    }
   }
-  // (a second, select-free copy of the selection for the all-live case costs more registers than it saves
-  // instructions: 168 VGPRs + 21 spilled against 145)
-  resolve_reg<KMAX>(sc, K > 0 ? K : 1, q);   // the reward needs the nearest even when K = 0
+  SALP_COUNT(2, true);
+  SALP_COUNT(3, all_live);
+  if (__any(q.tie)) {
+    // A swimmer that has not moved since its reset (zero velocity: legacy:95-117 until the first thrust, ~135 steps) sees the
+    // same foods from the same pose on every step, so a near tie recurs on all of them with the same answer: the exact
+    // order is computed once per episode and remembered (`order_cache`: K slot numbers, 4 bits each; < 0: none; the
+    // kernel drops it whenever the env's food set changes or it is reset).  Without this a wavefront with one such lane
+    // runs the exact pass on 135 of its steps, and a launch ends with its slowest wavefront.
+    const bool resting = (e.vx == 0.0) && (e.vy == 0.0);
+    const bool cached = q.tie && resting && (order_cache >= 0);
+    SALP_COUNT(0, __any(q.tie && !cached));
+    if (__any(q.tie && !cached)) {
+      exact_order_reg<FMAX, KMAX>(e, dist, Ksel, q);        // every lane: the exact order is the order
+      int pack = 0;
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) pack |= (q.idx[s] & 15) << (4 * s);
+      order_cache = resting ? pack : order_cache;
+    }
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+      const int k = (order_cache >> (4 * s)) & 15;
+      q.idx[s] = cached ? (k == 15 ? -1 : k) : q.idx[s];
+    }
+  }
+  if (all_live) resolve_f32<KMAX, true>(m, Ksel, xf, yf, q);
+  else resolve_f32<KMAX, false>(m, Ksel, xf, yf, q);
   {
     const double mg = CV(margin);
     o.collision = (e.x - r <= mg) || (e.x + r >= CV(wall_hi_x)) || (e.y - r <= mg) || (e.y + r >= CV(wall_hi_y));
@@ -179,10 +419,10 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, const OffsetLds& s
 // step).  An accepted point is wave-uniform and belongs in ONE lane's slot `slot` (wave-uniform as well): written as
 // `for k: if (slot == k) if (lane == L) fx[k] = ax` the compiler predicates all FMAX bodies — 97 instructions per
 // accepted food at 12 slots, ~1200 per reset — so the points of a batch go to the scratch (one LDS store each) and
-// lane L takes them into its registers once per batch (~8 instructions per filled slot).
-template <int FMAX, bool STD>
-__device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, int lane, const DevParams& P, uint64_t genv, int todo, int limit,
-                                                    double2* scratch) {
+// lane L takes them into its registers (and its mirror column) once per batch (~8 instructions per filled slot).
+template <int FMAX, bool STD, bool INREG>
+__device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, FoodF32<FMAX, INREG>& ff, const MirrorLds& m, int lane, const DevParams& P, uint64_t genv,
+                                                    int todo, int limit, double2* scratch) {
   unsigned long long need = __ballot(todo > 0);
   const double min2 = CV(min_food_dist2);
   // empty slots of the own env as a bit mask (bit k: slot k < F is empty)
@@ -203,7 +443,7 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, int lane, cons
     int attempts = 0;
     while (todo_l > 0) {
       // 64 candidates: draw number consumed + lane
-      const U4 w = philox4x32_10(g_lo, g_hi, rng0 + consumed + (uint32_t)lane, 0u, P.seed_lo, P.seed_hi);
+      const U4 w = philox4x32_10(g_lo, g_hi, rng0 + consumed + (uint32_t)lane, 0u, P.seed[0], P.seed[1]);
       const double x = CV(food_xlo) + CV(food_xspan) * u53(w.x, w.y);
       const double y = CV(food_ylo) + CV(food_yspan) * u53(w.z, w.w);
       bool ok;
@@ -251,7 +491,7 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, int lane, cons
         for (int k = 0; k < FMAX; ++k) {
           if ((filled >> k) & 1u) {                // wave-uniform
             const double2 v = scratch[k];          // same address in every lane: LDS broadcast
-            if (lane == L) { e.fx[k] = v.x; e.fy[k] = v.y; }
+            if (lane == L) { e.fx[k] = v.x; e.fy[k] = v.y; ff.set(k, v.x, v.y); m.set(k, v.x, v.y); }
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

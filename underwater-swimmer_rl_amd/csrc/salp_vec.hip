@@ -31,19 +31,9 @@ using namespace salp;
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-#ifndef SALP_BLOCK
-#define SALP_BLOCK 256
-#endif
-constexpr int kBlock = SALP_BLOCK;
+constexpr int kBlock = 256;
 constexpr int kWave = 64;
-#ifndef SALP_ALLFOUND_OBS
-#define SALP_ALLFOUND_OBS 1
-#endif
-#ifdef SALP_EXP_WAVES4
-#define SALP_MULTI_WAVES 4
-#else
-#define SALP_MULTI_WAVES 3     // multi-food kernels (<= 12 slots): <= 168 VGPRs, 3 wavefronts per SIMD
-#endif
+#define SALP_MULTI_WAVES 3     // multi-food kernels (<= 12 slots): <= 168 VGPRs, 3 wavefronts per SIMD (a fourth: +0.7 %, r02 session 10)
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -83,6 +73,7 @@ __device__ uint32_t salp_stamp_out[kStampWaves * 16];
 struct ColdBlock {
   DevParams P;
   DevState S;
+  uint32_t seed[2];   // the key of the draw streams: P.seed (in every copy of P) points here
 };
 
 // FULL = the common rollout signature (act, obs, reward, terminated, truncated all present; no
@@ -104,30 +95,23 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   // XOR-ed by bit 2 of the row — conflict-free for the row writes AND for the flush reads (profiles/isa_lds_model.py;
   // the 112-B padded pitch of round 1 was conflict-free for the writes only: 2-way on the reads).
   // Other K (generic instantiation, Q possibly odd): the padded pitch.
-#ifdef SALP_EXP_PAD_TILE
-  constexpr bool SWZ = false;
-#else
   constexpr bool SWZ = (KMAX == 3);
-#endif
   constexpr int PITCH = SWZ ? 4 * QMAX : 4 * QMAX + 4;     // LDS row pitch in floats
-  // Where the food positions of a multi-food env live: up to 12 slots in VGPRs (salp_food_reg.h: the pass
-  // leaves each slot's (dx, dy) in a per-wavefront LDS block), above that in LDS (salp_food_lds.h); one food is plain registers.
-#ifdef SALP_EXP_LDS_FOOD      // experiment build: the LDS-resident form for every multi-food kernel
-  constexpr bool REGF = false;
-  constexpr bool LDSF = FMAX > 1;
-#else
+  // Where the food positions of a multi-food env live: up to 12 slots in VGPRs with an fp32 mirror in LDS
+  // (salp_food_reg.h), above that in LDS (salp_food_lds.h); one food is plain registers.
   constexpr bool REGF = FMAX > 1 && FMAX <= 12;
   constexpr bool LDSF = FMAX > 12;
-#endif
   constexpr bool MULTI = REGF || LDSF;
   __shared__ __attribute__((aligned(16))) double2 food_lds[LDSF ? (kBlock / kWave) * FMAX * kWave : 1];
-  // Per-wavefront LDS region: the observation tile (64 rows) — and, for the register-food kernels, the (dx, dy)
-  // offsets of the pass (16 B per slot and lane, salp_food_reg.h) in the SAME bytes: the offsets live for the middle
-  // of a step (pass -> selection), the tile for its end (row writes -> flush).  LDS operations of a wavefront
-  // execute in order; a wavefront fence separates the two uses for the compiler.  12 slots: 12288 B per wavefront.
-  constexpr int WAVE_FLOATS = (REGF && 4 * FMAX > PITCH) ? kWave * 4 * FMAX : kWave * PITCH;
+  // Per-wavefront LDS region: the observation tile (64 rows of PITCH floats) and, for the register-food kernels, the
+  // fp32 mirror of the food positions behind it (8 B per slot and lane, salp_food_reg.h; lives for the whole launch).
+  // 12 slots, K = 3: 6144 + 6144 B per wavefront, 49 KB per workgroup -> 3 workgroups per CU.  The tile's bytes, idle in
+  // the middle of a step, are lent to the rare paths as scratch: the exact order's distances (8 B per slot and lane,
+  // <= the tile for every instantiation) and the placement's accepted points.
+  constexpr int TILE_FLOATS = kWave * PITCH;
+  constexpr int WAVE_FLOATS = TILE_FLOATS + (REGF ? kWave * 2 * FMAX : 0);
+  static_assert(!REGF || 2 * FMAX <= PITCH, "the exact order's [FMAX][64] doubles must fit in the tile");
   __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * WAVE_FLOATS];
-  constexpr bool ALIAS_OFFS = REGF;
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -182,9 +166,12 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   using EnvT = std::conditional_t<LDSF, EnvCore, Env<FMAX>>;
   EnvT e;
   const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
-  const OffsetLds offs{reinterpret_cast<double2*>(tile) + lane};   // REGF only
+  const MirrorLds mir{reinterpret_cast<float2*>(tile + TILE_FLOATS) + lane};   // REGF only
+  double* const dist_col = reinterpret_cast<double*>(tile) + lane;            // REGF only: exact_order_reg's scratch
+  FoodF32<REGF ? FMAX : 1, KMAX == 3> ff;   // REGF: fp32 roundings of the food positions (salp_food_reg.h)
   FoodScan<KMAX> fq;          // MULTI: nearest-K selection of the current food set around the current pose
   int nlive = 0;              // MULTI: live foods of this env, recounted whenever the food set changes
+  int order_cache = -1;       // REGF: remembered exact order of a resting swimmer's foods (step_env_reg)
   if constexpr (LDSF) {
     load_core(e, S, P, envc);
     for (int k = 0; k < P.F; ++k) {
@@ -197,7 +184,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     load_env(e, S, P, envc);
     if constexpr (REGF) {
 #pragma unroll
-      for (int k = 0; k < FMAX; ++k) nlive += is_none(e.fx[k]) ? 0 : 1;
+      for (int k = 0; k < FMAX; ++k) {
+        nlive += is_none(e.fx[k]) ? 0 : 1;
+        ff.set(k, e.fx[k], e.fy[k]);
+        mir.set(k, e.fx[k], e.fy[k]);
+      }
     }
   }
 
@@ -215,14 +206,12 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
   const int Hrun = (rows > 0) ? H : 0;   // a wavefront past the end of the range runs zero steps
-#ifdef SALP_EXP_BLOCK_SYNC
-  const bool block_full = env_begin + ((int64_t)blockIdx.x + 1) * kBlock <= env_end;
-#endif
 #ifdef SALP_EXP_STAMPS
   StampAcc stamps;
   for (int i = 0; i < 12; ++i) stamps.acc[i] = 0u;
   stamps.last = (uint32_t)__builtin_amdgcn_s_memtime();
   StampAcc* const stamps_ = &stamps;
+  const uint32_t stamp_real0 = (uint32_t)__builtin_amdgcn_s_memrealtime();   // 100 MHz: wall clock of the wavefront's loop
 #endif
 #pragma unroll 1
   for (int t = 0; t < Hrun; ++t) {
@@ -232,8 +221,8 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       // device action stream (include/salp_vec.h "Randomness"): word ts & 3 of block ts >> 2
       const uint32_t ts = (uint32_t)(io.global_step + t);
       if (t == 0 || (ts & 3u) == 0u) {   // wave-uniform
-        aw0 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 1u, P.seed_lo, P.seed_hi);
-        if (!FORCED) aw1 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 2u, P.seed_lo, P.seed_hi);
+        aw0 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 1u, P.seed[0], P.seed[1]);
+        if (!FORCED) aw1 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 2u, P.seed[0], P.seed[1]);
       }
       const uint32_t k = ts & 3u;
       const uint32_t w0 = (k == 0) ? aw0.x : (k == 1) ? aw0.y : (k == 2) ? aw0.z : aw0.w;
@@ -250,13 +239,8 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       }
     } else {  // prefetch the next step's action (the last step re-reads its own: keeps the load unconditional)
       const int64_t nb = (rowbase + ((t + 1 < H) ? P.n : 0) + envc) * AD;
-#ifdef SALP_EXP_ACT_NT   // experiment: the action read as a streaming (non-temporal) load
-      a0 = __builtin_nontemporal_load(&io.act[nb]);
-      if (!FORCED) a1 = __builtin_nontemporal_load(&io.act[nb + 1]);
-#else
       a0 = io.act[nb];
       if (!FORCED) a1 = io.act[nb + 1];
-#endif
     }
 
 #ifdef SALP_EXP_STORE_ONLY   // experiment build: no simulation, only the output stream
@@ -268,9 +252,9 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     else if constexpr (REGF) {
 #ifdef SALP_EXP_STAMPS
       { StampAcc* stamps_ = &stamps; SALP_STAMP(0); }
-      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, offs, P, genv, c0, c1, K, fq, nlive, &cold->P, &stamps);
+      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, ff, mir, dist_col, P, genv, c0, c1, K, fq, nlive, order_cache, &cold->P, &stamps);
 #else
-      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, offs, P, genv, c0, c1, K, fq, nlive, &cold->P);
+      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, ff, mir, dist_col, P, genv, c0, c1, K, fq, nlive, order_cache, &cold->P);
 #endif
     }
     else o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
@@ -279,30 +263,14 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     double rmax = o.rmax;
     bool have_rel = o.rel_valid;
 
-#ifdef SALP_EXP_NO_SMALL_STORES
-    if (rows < 0)
-#endif
     if (active) {
       // reward: one dword per lane (256 B per wavefront); flags: one byte per lane.  (Rebuilding the
       // 64 flag bytes from a ballot and storing 16 dwords was measured: no faster in the memory
       // pipeline and slower overall, profiles/r01/ab_notes.md.)
-#ifdef SALP_EXP_SMALL_STORE_BITS   // experiment: cache-policy bits of the reward / flag stores (FULL, unpredicated kernels)
-      if constexpr (FULL && !RAGGED) {
-        const float rv = o.reward;
-        const int tv_ = o.terminated ? 1 : 0, uv_ = o.truncated ? 1 : 0;
-        asm volatile("global_store_dword %0, %1, off " SALP_EXP_SMALL_STORE_BITS :: "v"(&io.reward[rowbase + env]), "v"(rv) : "memory");
-        asm volatile("global_store_byte %0, %1, off " SALP_EXP_SMALL_STORE_BITS :: "v"(&io.terminated[rowbase + env]), "v"(tv_) : "memory");
-        asm volatile("global_store_byte %0, %1, off " SALP_EXP_SMALL_STORE_BITS :: "v"(&io.truncated[rowbase + env]), "v"(uv_) : "memory");
-      } else
-#endif
-#ifdef SALP_EXP_LATE_SMALL_STORES   // experiment: reward / flags stored right AFTER the observation rows (FULL kernels)
-      if constexpr (!FULL)
-#endif
-      {
+      // (cache-policy bits on these small stores, and issuing them after the rows: measured, slower — r02 sessions 11, 14, 15)
       if (FULL || io.reward) io.reward[rowbase + env] = o.reward;
       if (FULL || io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
       if (FULL || io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
-      }
       if (!FULL && io.info) {
         int32_t* ip = io.info + (rowbase + env) * SALP_INFO_COLS;
         ip[SALP_INFO_FOOD_COLLECTED] = e.fc;
@@ -323,6 +291,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
 #endif
       const DevParams& C = cold->P;   // rare path: constants from memory, not from scalar registers
       int limit = 50;
+      if (o.collected || done) order_cache = -1;      // the food set (or the episode) changes
       if (active && io.stats) {
         if (o.collected) atomicAdd(&blk_stats[ST_FOOD], 1ull);
         if (o.collision) atomicAdd(&blk_stats[ST_COLL], 1ull);
@@ -342,12 +311,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
             if constexpr (LDSF) {   // the terminal observation sees the respawned food (pass 0)
               bool c_; int h_;
               scan_foods<KMAX, false, true>(food, C.F, e.x, e.y, 0.0, fq, c_, h_, nlive);
+              if (__any(fq.tie)) exact_order_lds<KMAX>(food, C.F, K, e.x, e.y, fq);
               resolve<KMAX>(food, K, e.x, e.y, fq);
               observe_lds<KMAX, STD>(e, C, rmax, K, fq, nlive, false, 0.f, fo);
             } else if constexpr (REGF) {
-              bool c_; int h_;
-              scan_foods_reg<FMAX, KMAX, false, true>(e, offs, C.F, 0.0, fq, c_, h_, nlive);
-              resolve_reg<KMAX>(offs, K, fq);
+              select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, dist_col, K, CV(tie_c0), fq, nlive);
               observe_lds<KMAX, STD>(e, C, rmax, K, fq, nlive, false, 0.f, fo);
             } else {
               observe<FMAX, KMAX, STD>(e, C, rmax, have_rel, o.rel, fo);
@@ -362,14 +330,15 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
             for (int k = 0; k < C.F; ++k) food.clear(k);
           } else {
             todo = reset_pose<FMAX, STD>(e, C, genv, F_base);
+            if constexpr (REGF) {
+#pragma unroll
+              for (int k = 0; k < FMAX; ++k) { ff.clear(k, true); mir.clear(k); }
+            }
           }
           limit = 100;
           rmax = CV(R);
           have_rel = false;
         }
-#ifdef SALP_EXP_SERIAL_PLACE
-        if constexpr (LDSF) place_food_lds<STD>(e, food, C, genv, todo, limit);
-#else
         if constexpr (LDSF) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
@@ -379,8 +348,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-#endif
-        else if constexpr (REGF) place_food_coop_reg<FMAX, STD>(e, lane, C, genv, todo, limit, reinterpret_cast<double2*>(tile));
+        else if constexpr (REGF) place_food_coop_reg<FMAX, STD, KMAX == 3>(e, ff, mir, lane, C, genv, todo, limit, reinterpret_cast<double2*>(tile));
         else place_food<FMAX, STD>(e, C, genv, todo, limit);
         todo = 0;
       }
@@ -388,15 +356,12 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       if constexpr (LDSF) {   // the food set (or the pose) changed: select again for the observation
         bool c_; int h_;
         scan_foods<KMAX, false, true>(food, C.F, e.x, e.y, 0.0, fq, c_, h_, nlive);
+        if (__any(fq.tie)) exact_order_lds<KMAX>(food, C.F, K, e.x, e.y, fq);
         resolve<KMAX>(food, K, e.x, e.y, fq);
         have_rel = false;
       }
-      if constexpr (REGF) {
-        // (inserting the one respawned food into the capture pass's list instead of a second pass over all slots
-        // saves ~200 instructions on ~7 % of the steps on paper and measured 0.6-1.7 % SLOWER twice: ab_notes.md session 15)
-        bool c_; int h_;
-        scan_foods_reg<FMAX, KMAX, false, true>(e, offs, C.F, 0.0, fq, c_, h_, nlive);
-        resolve_reg<KMAX>(offs, K, fq);
+      if constexpr (REGF) {   // likewise (the exact order's scratch and the placement's are the same idle tile bytes, used in turn)
+        select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, dist_col, K, CV(tie_c0), fq, nlive);
         have_rel = false;
       }
     }
@@ -406,25 +371,12 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       float ob[12 + 4 * KMAX];
       if constexpr (REGF) {
         // all FMAX slots of every lane alive (the steady state with respawn) => every lane shows K foods
-        if (SALP_ALLFOUND_OBS && (KMAX <= FMAX) && K >= 1 && __all(nlive == FMAX)) observe_lds<KMAX, STD, true>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
+        if ((KMAX <= FMAX) && K >= 1 && __all(nlive == FMAX)) observe_lds<KMAX, STD, true>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
         else observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
       } else if constexpr (LDSF) observe_lds<KMAX, STD>(e, P, rmax, K, fq, nlive, have_rel, o.rel, ob);
       else observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
       SALP_STAMP(8);
-#ifdef SALP_EXP_DIRECT_STORE   // experiment: per-lane 96-B rows straight from registers (no LDS transpose)
-      if (active) {
-        float4* drow = reinterpret_cast<float4*>(io.obs + (rowbase + env) * OD);
-#pragma unroll
-        for (int q = 0; q < QMAX; ++q)
-          if (q < Q) drow[q] = make_float4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
-      }
-      if (rows < 0)
-#endif
-      if constexpr (ALIAS_OFFS) {   // the selection's offset reads come before the row writes to the same bytes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
+      // (per-lane 96-B rows stored straight from registers, without the LDS transpose: 2.1x slower, r01 ab_notes)
 #pragma unroll
       for (int q = 0; q < QMAX; ++q)   // 16-B LDS stores, conflict-free (see the tile layout above)
         if (q < Q) ((q & 1) ? myrow_odd : myrow_even)[q] = make_float4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
@@ -432,9 +384,6 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       v4f* gout = reinterpret_cast<v4f*>(io.obs + (rowbase + env0) * OD) + lane;
-#ifdef SALP_EXP_NO_OBS_STORE    // experiment build: everything but the observation stream
-      if (rows < 0)
-#endif
       {
         v4f tv[QMAX];
 #pragma unroll
@@ -446,16 +395,17 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
         // __builtin_nontemporal_store emits and what was -2.4 % against plain stores (profiles/r02/ab_notes.md
         // session 14).  The compiler has no builtin for the scope bits of a plain global store, hence the asm; its
         // waitcnt pass does not count these stores, which is safe: vmcnt retires in order, so a wait computed
-        // without them can only wait longer, and nothing reads the stream back.
-#ifndef SALP_OBS_STORE_BITS
-#define SALP_OBS_STORE_BITS "sc1 nt"
-#endif
+        // without them can only wait longer, and nothing reads the stream back.  The hazard recogniser does not see
+        // them either: gfx9 wants one wait state between a store of more than 64 bits and a VALU write of its data
+        // registers, so the last store carries an `s_nop 0` (the end-of-step drain below follows anyway: !MULTI).
         if constexpr (!RAGGED && QMAX == 6 && !MULTI) {   // the write-bound one-food kernel; the VALU-bound multi-food ones: +1 %, not used
           v4f* const gout4 = gout + 4 * kWave;     // the instruction's immediate offset reaches 4095 B: two bases
 #pragma unroll
-          for (int j = 0; j < QMAX; ++j)
-            asm volatile("global_store_dwordx4 %0, %1, off offset:%2 " SALP_OBS_STORE_BITS
+          for (int j = 0; j < QMAX - 1; ++j)
+            asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1 nt"
                          :: "v"(j < 4 ? gout : gout4), "v"(tv[j]), "n"((j & 3) * kWave * 16) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1 nt\n\ts_nop 0"
+                       :: "v"(gout4), "v"(tv[QMAX - 1]), "n"(((QMAX - 1) & 3) * kWave * 16) : "memory");
         } else
 #pragma unroll
         for (int j = 0; j < QMAX; ++j)
@@ -465,38 +415,20 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-#ifdef SALP_EXP_LATE_SMALL_STORES
-    if constexpr (FULL) {
-      if (active) {
-        io.reward[rowbase + env] = o.reward;
-        io.terminated[rowbase + env] = o.terminated ? 1 : 0;
-        io.truncated[rowbase + env] = o.truncated ? 1 : 0;
-      }
-    }
-#endif
-#ifdef SALP_EXP_VMCNT
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SALP_EXP_VMCNT) : "memory");
-#elif !defined(SALP_EXP_NO_DRAIN)
     // One-food kernel (write-bound): drain this step's stores before the next step.  Measured
     // (profiles/r01/ab_notes.md): letting stores run ahead (vmcnt(9)) is 2-6 % SLOWER than draining —
     // wavefronts that stay in step keep the write stream of all CUs inside one contiguous [N x 96 B] slab
     // at a time.  The multi-food kernels are issue-bound at 2 wavefronts per SIMD: there the drain is a
     // stall nothing hides (-6.4 % without it, profiles/r02/ab_notes.md session 2).
-#ifdef SALP_EXP_DRAIN_ALL
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-#else
     if constexpr (!MULTI) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-#endif
-#endif
-#ifdef SALP_EXP_BLOCK_SYNC
-    if (block_full) __syncthreads();
-#endif
     SALP_STAMP(9);
   }
 #ifdef SALP_EXP_STAMPS
   if (lane == 0 && rows > 0) {
     const int gw = (int)((env0 - env_begin) / kWave) & (kStampWaves - 1);
     for (int i = 0; i < 12; ++i) salp_stamp_out[gw * 16 + i] = stamps.acc[i];
+    salp_stamp_out[gw * 16 + 12] = stamp_real0;                                           // start (10-ns ticks, low word)
+    salp_stamp_out[gw * 16 + 13] = (uint32_t)__builtin_amdgcn_s_memrealtime();            // end
   }
 #endif
 
@@ -544,8 +476,8 @@ __global__ __launch_bounds__(kBlock) void salp_gen_actions_kernel(DevParams P, f
   for (int t = 0; t < H; ++t) {
     const uint32_t ts = (uint32_t)(global_step + t);
     if (t == 0 || (ts & 3u) == 0u) {
-      w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 1u, P.seed_lo, P.seed_hi);
-      if (AD == 2) w2 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 2u, P.seed_lo, P.seed_hi);
+      w = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 1u, P.seed[0], P.seed[1]);
+      if (AD == 2) w2 = philox4x32_10((uint32_t)genv, (uint32_t)(genv >> 32), ts >> 2, 2u, P.seed[0], P.seed[1]);
     }
     const uint32_t k = ts & 3u;
     const uint32_t x0 = (k == 0) ? w.x : (k == 1) ? w.y : (k == 2) ? w.z : w.w;
@@ -646,6 +578,21 @@ __global__ void salp_set_state_kernel(DevParams P, DevState S, const double* f64
   }
 }
 
+// salp_vec_reseed: the state a freshly created handle has before its initial reset (every row zero, draw counters
+// included), the new key words, cleared statistics.  The reset kernel that follows on the same stream reads the new key.
+__global__ __launch_bounds__(kBlock) void salp_reseed_kernel(ColdBlock* cold, DevStats* stats, int64_t pitch, int nf_rows,
+                                                            uint32_t seed_lo, uint32_t seed_hi) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < pitch) {
+    double* f = cold->S.f;
+    int32_t* w = cold->S.i;
+    for (int r = 0; r < nf_rows; ++r) f[(int64_t)r * pitch + i] = 0.0;
+    for (int r = 0; r < SI_COUNT; ++r) w[(int64_t)r * pitch + i] = 0;
+  }
+  if (i == 0) { cold->seed[0] = seed_lo; cold->seed[1] = seed_hi; }
+  if (i < (int64_t)SALP_STATS_REPLICAS * 16) stats[i / 16].v[i % 16] = 0ull;
+}
+
 // ------------------------------------------------------------------ host side
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -695,6 +642,7 @@ struct salp_vec {
   float* act_buf;        // device-generated actions when the caller gives no act_out
   size_t act_bytes;
   size_t nf_rows;
+  hipStream_t last_stream;   // the stream of the handle's most recent launch: what get_stats / destroy wait for
 };
 
 namespace {
@@ -724,6 +672,7 @@ DevParams make_params(const salp_config_t& c, int64_t n, int64_t pitch, uint64_t
   P.inv_W = 1.0 / P.W; P.inv_H = 1.0 / P.H; P.inv_pi = 1.0 / 3.141592653589793;
   P.inv_R = 1.0 / c.base_radius; P.inv_max_nozzle = 1.0 / c.max_nozzle_angle;
   P.inv_diag = (float)(1.0 / sqrt(P.W * P.W + P.H * P.H));
+  { const double L = P.W > P.H ? P.W : P.H; P.tie_c0 = (float)(1.4e-7 * L * L); }
   P.inhale_dur = c.inhale_duration; P.exhale_dur = c.exhale_duration;
   P.cycle_len = c.inhale_duration + c.exhale_duration + c.rest_duration;
   P.max_steps_wo_food = c.max_steps_without_food;
@@ -732,7 +681,7 @@ DevParams make_params(const salp_config_t& c, int64_t n, int64_t pitch, uint64_t
   P.forced = c.forced_breathing != 0; P.random_food_count = c.random_food_count != 0;
   P.respawn = c.respawn_food != 0;
   P.autoreset = c.no_autoreset == 0;
-  P.seed_lo = (uint32_t)seed; P.seed_hi = (uint32_t)(seed >> 32);
+  P.seed = nullptr;   // set by salp_vec_create once the ColdBlock exists
   P.env_base = (uint64_t)base; P.n = n; P.pitch = pitch;
   return P;
 }
@@ -818,7 +767,7 @@ bool is_std(const DevParams& P) {
          P.min_food_dist2 == C::min_food_dist2 && P.food_xlo == C::food_xlo && P.food_xspan == C::food_xspan &&
          P.food_ylo == C::food_ylo && P.food_yspan == C::food_yspan && P.inv_W == C::inv_W && P.inv_H == C::inv_H &&
          P.inv_pi == C::inv_pi && P.inv_R == C::inv_R && P.inv_max_nozzle == C::inv_max_nozzle &&
-         P.inv_diag == C::inv_diag && P.inhale_dur == C::inhale_dur && P.exhale_dur == C::exhale_dur &&
+         P.inv_diag == C::inv_diag && P.tie_c0 == C::tie_c0 && P.inhale_dur == C::inhale_dur && P.exhale_dur == C::exhale_dur &&
          P.cycle_len == C::cycle_len;
 }
 
@@ -933,8 +882,10 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
   }
   hipError_t e4 = hipMalloc((void**)&h->cold, sizeof(ColdBlock));
   if (e4 == hipSuccess) {
+    h->P.seed = (seed_word_t*)(uintptr_t)h->cold->seed;   // device address; the kernels read the key words through it
     ColdBlock cb;
     cb.P = h->P; cb.S = h->S;
+    cb.seed[0] = (uint32_t)seed; cb.seed[1] = (uint32_t)(seed >> 32);
     e4 = hipMemcpy(h->cold, &cb, sizeof(cb), hipMemcpyHostToDevice);
   }
   if (e4 != hipSuccess) {
@@ -952,8 +903,8 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
   }
   // initial reset of every env (consumes the first draws of each env's stream)
   rc = salp_vec_reset(h, nullptr, nullptr, SALP_DEVICE_PTRS, nullptr);
-  if (rc == SALP_OK) {
-    hipError_t es = hipDeviceSynchronize();
+  if (rc == SALP_OK) {   // the handle's own work only (the null stream it was issued on), not a device-wide drain
+    hipError_t es = hipStreamSynchronize(nullptr);
     if (es != hipSuccess) rc = fail(SALP_ERR_HIP, std::string("initial reset: ") + hipGetErrorString(es));
   }
   if (rc != SALP_OK) { std::string m = g_err; salp_vec_destroy(h); g_err = m; return rc; }
@@ -965,6 +916,7 @@ void salp_vec_destroy(salp_vec_t* h) {
   if (!h) return;
   DeviceScope dev_scope;
   (void)dev_scope.enter(h->device);
+  (void)hipStreamSynchronize(h->last_stream);     // hipFree does not wait for kernels on non-blocking streams
   if (h->S.f) (void)hipFree(h->S.f);
   if (h->S.i) (void)hipFree(h->S.i);
   if (h->stats) (void)hipFree(h->stats);
@@ -984,6 +936,11 @@ int salp_exp_read_stamps(uint32_t* dst, int words) {
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(salp_stamp_out), n, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef SALP_EXP_COUNT
+int salp_exp_read_counters(unsigned long long* dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(salp_exp_counter), 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 int salp_vec_num_food(const salp_vec_t* h) { return h ? h->F : 0; }
 int salp_vec_device(const salp_vec_t* h) { return h ? h->device : -1; }
 int64_t salp_vec_global_step(const salp_vec_t* h) { return h ? h->global_step : 0; }
@@ -1001,6 +958,7 @@ int salp_vec_reset(salp_vec_t* h, const uint8_t* mask, float* obs, uint32_t flag
   DeviceScope dev_scope;
   HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
+  h->last_stream = st;
   const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
   reset_fn fn = reset_kernel_for(h);
   if (flags & SALP_DEVICE_PTRS) {
@@ -1027,6 +985,7 @@ int salp_vec_observe(salp_vec_t* h, float* obs, uint32_t flags, void* stream) {
   DeviceScope dev_scope;
   HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
+  h->last_stream = st;
   const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
   reset_fn fn = reset_kernel_for(h);
   if (flags & SALP_DEVICE_PTRS) {
@@ -1053,6 +1012,7 @@ static int rollout_impl(salp_vec_t* h, const float* act, int32_t H, float* obs, 
   DeviceScope dev_scope;
   HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
+  h->last_stream = st;
   IOPtrs io;
   memset(&io, 0, sizeof(io));
   io.stats = h->stats_enabled ? h->stats : nullptr;
@@ -1137,6 +1097,7 @@ int salp_vec_get_state(salp_vec_t* h, double* f64, int32_t* i32, uint32_t flags,
   DeviceScope dev_scope;
   HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
+  h->last_stream = st;
   const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
   const size_t fb = (size_t)SALP_F_COUNT(h->F) * h->n * sizeof(double);
   const size_t ib = (size_t)SALP_I_COUNT * h->n * sizeof(int32_t);
@@ -1163,6 +1124,7 @@ int salp_vec_set_state(salp_vec_t* h, const double* f64, const int32_t* i32, uin
   DeviceScope dev_scope;
   HIP_TRY(dev_scope.enter(h->device));
   hipStream_t st = (hipStream_t)stream;
+  h->last_stream = st;
   const unsigned grid = (unsigned)((h->n + kBlock - 1) / kBlock);
   const size_t fb = (size_t)SALP_F_COUNT(h->F) * h->n * sizeof(double);
   const size_t ib = (size_t)SALP_I_COUNT * h->n * sizeof(int32_t);
@@ -1188,9 +1150,11 @@ int salp_vec_get_stats(salp_vec_t* h, salp_stats_t* out) {
   if (!h || !out) return fail(SALP_ERR_INVALID, "handle/out is NULL");
   DeviceScope dev_scope;
   HIP_TRY(dev_scope.enter(h->device));
-  HIP_TRY(hipDeviceSynchronize());
+  // The totals are complete once the handle's most recent launch is: wait for ITS stream (in-order), not for the
+  // device — a device-wide drain here would also stall every other stream of the process (RCCL collectives in flight).
   DevStats host[SALP_STATS_REPLICAS];
-  HIP_TRY(hipMemcpy(host, h->stats, sizeof(host), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpyAsync(host, h->stats, sizeof(host), hipMemcpyDeviceToHost, h->last_stream));
+  HIP_TRY(hipStreamSynchronize(h->last_stream));
   long long acc[16] = {0};
   for (int r = 0; r < SALP_STATS_REPLICAS; ++r)
     for (int k = 0; k < 16; ++k) acc[k] += (long long)host[r].v[k];
@@ -1206,9 +1170,25 @@ int salp_vec_clear_stats(salp_vec_t* h) {
   if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
   DeviceScope dev_scope;
   HIP_TRY(dev_scope.enter(h->device));
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(h->stats, 0, SALP_STATS_REPLICAS * sizeof(DevStats)));
+  // stream-ordered behind the handle's most recent launch: no host synchronisation at all
+  HIP_TRY(hipMemsetAsync(h->stats, 0, SALP_STATS_REPLICAS * sizeof(DevStats), h->last_stream));
   return SALP_OK;
+}
+
+int salp_vec_reseed(salp_vec_t* h, uint64_t seed, float* obs, uint32_t flags, void* stream) {
+  if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  h->last_stream = st;
+  const int64_t pitch = h->P.pitch;
+  const unsigned grid = (unsigned)((pitch + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(salp_reseed_kernel, dim3(grid), dim3(kBlock), 0, st, h->cold, h->stats, pitch, (int)h->nf_rows,
+                     (uint32_t)seed, (uint32_t)(seed >> 32));
+  HIP_TRY(hipGetLastError());
+  h->seed = seed;
+  h->global_step = 0;
+  return salp_vec_reset(h, nullptr, obs, flags, stream);   // every env, from draw counter 0 of the new streams
 }
 
 }  // extern "C"

@@ -9,7 +9,7 @@ Restates the protocol and metrics of the reference's eval/collect_navigation_dat
     reference's loop ignores `terminated` / `truncated`, so wall contacts do not end a trial (`no_autoreset`);
   * metrics (:117-196): path length (+ final distance to the goal), success (final distance < 50),
     path ratio, straightness, mean lateral deviation from the start-goal line, bounding-box area and
-    area ratio, x / y range.  (The reference's optional spline-smoothed path ratio is not restated.)
+    area ratio, x / y range, and the spline-smoothed path ratio (:138-165, `spline_path_length`).
 All trials run at once: trial i is env i.  The only published numbers for this protocol are in
 eval/results/navigation_stats_20251207_165158.json (a trained SB3 policy: success 1.00,
 1773.78 +/- 253.8 steps, path ratio 1.173, straightness 0.863).

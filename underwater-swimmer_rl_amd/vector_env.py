@@ -112,18 +112,18 @@ class SalpVectorEnv:
     # ------------------------------------------------------------------ Gymnasium surface
     def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None, mask=None):
         """Resets every env (or those in `mask`).  `seed` re-keys the draw streams (the reference's
-        reset(seed) only seeds gymnasium's unused np_random, snake:136)."""
+        reset(seed) only seeds gymnasium's unused np_random, snake:136): `salp_vec_reseed` — new key words, draw counters
+        at 0, every env reset, in place.  The C handle, its device state and this env's output buffers are kept (round 2
+        destroyed and re-created the handle: a hipGraph captured earlier then replayed into freed memory), so graphs from
+        `capture_policy_steps` / `train_sac_graphed` stay valid across `reset(seed=...)`; a poked base_num_food_items
+        survives.  A seed restarts EVERY env's stream, so it cannot be combined with a partial `mask`."""
         if seed is not None:      # any explicit seed restarts the draw streams: reset(seed=s) twice gives the same episodes
-            base_food = self._lib.base_num_food
-            self._lib.close()
+            if mask is not None and not bool(np.all(np.asarray(mask.cpu() if hasattr(mask, "cpu") else mask))):
+                raise ValueError("reset(seed=..., mask=...) with a partial mask: a seed re-keys the draw streams of ALL envs; "
+                                 "reseed with mask=None, or reset the subset without a seed")
             self.seed_value = int(seed)
-            self._lib = SalpLib(self.cfg, self.num_envs, self._device_index, self.seed_value, self.env_index_base)
-            if base_food != self.cfg.num_food_items:      # a poked base_num_food_items survives re-seeding
-                self._lib.set_base_num_food(base_food)
-                self._lib.reset(None, self._buf("obs", (self.num_envs, self.obs_dim), np.float32), self._flags, self._stream)
-            self._step_cache = None
             obs = self._buf("obs", (self.num_envs, self.obs_dim), np.float32)
-            self._lib.observe(obs, self._flags, self._stream)
+            self._lib.reseed(self.seed_value, obs, self._flags, self._stream)
             return obs, {}
         obs = self._buf("obs", (self.num_envs, self.obs_dim), np.float32)
         m = None
