@@ -55,3 +55,19 @@ def test_swizzled_observation_tile_is_conflict_free():
         for q in range(6):
             mine = lane * 96 + 16 * ((q - swz) if (q & 1) else (q + swz))
             assert mine == f(lane, q)
+
+
+def test_ellipse_a_is_the_larger_axis_for_the_reference_radii():
+    """csrc/salp_device.h step_head(): the literal-constant kernels take r = max(ellipse_a, ellipse_b) = ellipse_a
+    (legacy:190-246: a = 1.3R .. 1.1R .. 1.3R, b = 0.8R .. 1.1R .. 0.8R).  Every (phase, timer, duration) the state machine
+    can reach, in the kernel's own fp64 expressions (R = 30: a_rest 39, b_rest 24, full 33, slopes -6 / +9 / +6 / -9)."""
+    for t in range(0, 121):                       # inhaling, and the unchanged ellipse at release (water = t / 120)
+        p = t / 120
+        a, b = 39.0 + (-6.0) * p, 24.0 + 9.0 * p
+        assert a >= b, (t, a, b)
+    for dur in range(1, 256):                     # exhaling with any duration the packed word can hold
+        for t in range(1, dur + 1):
+            p = t / dur
+            a, b = 33.0 + 6.0 * p, 33.0 + (-9.0) * p
+            assert a >= b, (dur, t, a, b)
+    assert 33.0 + 6.0 * 1.0 >= 33.0 + (-9.0) * 1.0 and 39.0 >= 24.0     # last exhale step, rest

@@ -485,12 +485,10 @@ __device__ __forceinline__ ThrustTerms jet_thrust_terms(double th, double noz, d
   const double moment = mul_s(perp * arm, TT[TT_K00005]);
   const double shape = mul_s((nn * T) * water, TT[TT_K00003]);
   t.om = (primary + moment) + shape;
-  {  // side thrust at fl(phi + fl(pi/2)) = phi + pi/2 + dl,  dl = (fl(pi/2) - pi/2) - err
-    const double pio2 = TT[TT_PIO2];
-    const double side = phi + pio2;
-    const double bb = side - phi;
-    const double err = (phi - (side - bb)) + (pio2 - bb);   // phi + PIO2 = side + err exactly
-    const double dl = TT[TT_DL] - err;
+  {  // side thrust at fl(phi + fl(pi/2)) = phi + pi/2 + dl,  dl = fl(pi/2) - pi/2 (6.1e-17) up to the rounding of the sum
+     // (<= 4.4e-16: 4e-17 px per step through the 0.1-px side term, below the device sincos' own last-bit departure from
+     // glibc — round 2 recovered it with a TwoSum, six fp64 instructions per thrust step)
+    const double dl = TT[TT_DL];
     const double sc = -fma(dl, c, s);     // cos(side) = -sin(phi + dl)
     const double ss = fma(-dl, s, c);     // sin(side) =  cos(phi + dl)
     const double S = mul_s(T * fabs(noz), TT[TT_K03]);
@@ -505,10 +503,7 @@ __device__ __forceinline__ ThrustTerms jet_thrust_terms(double th, double noz, d
     const U4 w = philox4x32_10(g0, (uint32_t)(genv >> 32), rng, 0u, k0, k1);
     const double u = u53(w.x, w.y);
     const double d = mul_s(u - 0.5, TT[TT_K005]);
-    const double na = phi + d;
-    const double bb = na - phi;
-    const double err = (phi - (na - bb)) + (d - bb);
-    const double D = d - err;             // na = phi + D (to ~1e-18)
+    const double D = d;                   // fl(phi + d) = phi + D up to the sum's rounding (<= 4.4e-16 rad on a 3e-3-px term)
     const double z = D * D;
     double sp = fma_s(z, (double)TT[TT_J_S3], TT[TT_J_S2]);
     sp = fma_s(z, sp, TT[TT_J_S1]);
@@ -703,7 +698,12 @@ __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint
       }
     }
   }
-  const double r = pymax(a, b);
+  // max(ellipse_a, ellipse_b) is ellipse_a whenever both come from the formulas above with the reference's radii:
+  // a - b = R (0.5 - 0.5 p) inhaling, R 0.5 p exhaling, 0.5 R at rest, all >= 0 and exact in fp64 for R = 30 (a and b
+  // are multiples of 2^-46 below 64: every product and sum above is exact or rounds both the same way is NOT assumed —
+  // checked for every (phase, timer, duration) of the literal constants by tests/test_source_claims.py).  Other radii
+  // keep the maximum.
+  const double r = STD ? a : pymax(a, b);
 #ifdef SALP_EXP_NO_THRUST      // experiment build (profiles/ab_bench.py): price of the thrust block
   thrust = false;
 #endif
