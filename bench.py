@@ -129,6 +129,46 @@ def sac_first_capture(device, world: int, rank: int, envs: int = 4096, max_steps
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def secondary_kernels(device, envs: int, chunk: int, launches: int = 10, warmup: int = 3):
+    """The rollout kernels the headline does not run, timed the same way (HIP events on the launch stream around each
+    launch, inputs resident in HBM), AFTER the headline and outside its timed region: the 12-food kernel of the preset
+    BASELINE configs[4] names (configs/sac_gail.yaml:9 — the kernel furthest below its roofline).  At most
+    `warmup + launches` <= 15 launches per entry."""
+    import torch
+    import underwater_swimmer_rl_amd as pkg
+    from underwater_swimmer_rl_amd.vector_env import SalpVectorEnv
+    out = []
+    for preset in ("sac_gail",):
+        try:
+            cfg = pkg.load_env_config(preset)
+            env = SalpVectorEnv(cfg, envs, device=str(device), seed=0, env_index_base=0)
+            gen = torch.Generator(device=device)
+            gen.manual_seed(4321)
+            act = torch.rand((chunk, envs, cfg.act_dim), generator=gen, device=device, dtype=torch.float32) * 2.0 - 1.0
+            for _ in range(warmup):
+                env.rollout(act)
+            ms = []
+            for _ in range(launches):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); env.rollout(act); e.record(); e.synchronize()
+                ms.append(s.elapsed_time(e))
+            bpe = algorithmic_bytes_per_env_step(cfg, chunk)
+            avg = sum(ms) / len(ms)
+            ach = bpe * envs * chunk / (avg * 1e-3) / 1e9
+            out.append({"preset": preset, "kernel": f"salp_rollout_kernel<{12 if cfg.num_food_items > 8 else cfg.num_food_items},3> "
+                        f"({cfg.num_food_items} foods in VGPRs + fp32 mirror in LDS)", "envs": envs, "chunk": chunk,
+                        "launches": launches, "warmup": warmup, "avg_kernel_ms": avg, "min_kernel_ms": min(ms), "max_kernel_ms": max(ms),
+                        "achieved": ach, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS, "bound": "hbm (priced); VALU-issue (actual)",
+                        "algorithmic_bytes_per_env_step": bpe, "env_steps_per_launch": envs * chunk,
+                        "env_steps_per_s": envs * chunk / (avg * 1e-3), "food_collected": env.stats()["food_collected"]})
+            env.close()
+            del act
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001 — an extra, never the headline
+            out.append({"preset": preset, "error": f"{type(e).__name__}: {e}"})
+    return out
+
+
 CONFIG2_ENVS = 262144        # BASELINE configs[2]: one GPU
 CONFIG3_TOTAL_ENVS = 1048576  # BASELINE configs[3]: sharded over the GPUs of one node
 
@@ -173,7 +213,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sac-probe", action="store_true", help="skip the configs[4] first-food-capture probe")
-    ap.add_argument("--no-alt-modes", action="store_true", help="--gpus G > 1: do not also time --gather final / none after the headline")
+    ap.add_argument("--alt-modes", action="store_true", help="--gpus G > 1: also time --gather final / none after the headline "
+                    "(opt-in: the extra collectives have never run on more than one GPU; a failure is agreed across the ranks)")
+    ap.add_argument("--no-alt-modes", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary_kernels record (the 12-food kernel, after the headline)")
+    ap.add_argument("--probe-seconds", type=float, default=90.0, help="wall-clock limit of the extras that run before the line is printed")
     ap.add_argument("--sac-probe", action="store_true", help="--gpus G > 1: run the configs[4] probe data-parallel on every rank "
                     "(off by default there: that path — graph segments + RCCL gradient all-reduces — is covered by gloo and "
                     "world-size-1 tests only, and a scaling run must not depend on it)")
@@ -330,7 +374,10 @@ def main():
     bpe = algorithmic_bytes_per_env_step(cfg, H)
     achieved_gbs = bpe * n * H / avg_kernel_s / 1e9
 
-    traffic = None
+    # HBM bytes per launch from the PMC counters of the committed profile of this workload: WRITE_SIZE + 2 x FETCH_SIZE
+    # (on gfx950 FETCH_SIZE reports half the bytes read, MI355X_MICROARCH.md §HBM: the raw figure is BELOW the action
+    # bytes the kernel must read); the raw sum is kept beside it.
+    traffic = traffic_raw = None
     tp = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.isfile(tp):
         try:
@@ -338,8 +385,9 @@ def main():
                 tj = json.load(f)
             if tj.get("envs") == n and tj.get("chunk") == H and tj.get("preset") == args.preset:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_raw = tj.get("hbm_bytes_per_launch_raw")
         except Exception:
-            traffic = None
+            traffic = traffic_raw = None
 
     line = {
         "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
@@ -361,8 +409,9 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw_fetch": traffic_raw,
             "kernel": "salp_rollout_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+            "min_kernel_ms": min(kernel_ms), "max_kernel_ms": max(kernel_ms),
             "algorithmic_bytes_per_env_step": bpe, "env_steps_per_launch": n * H,
         },
         "episodes_finished": stats["episodes"], "food_collected": stats["food_collected"],
@@ -379,47 +428,86 @@ def main():
             "note": "the all-gather of every returned observation moves (G-1) x chunk x N/G x obs_dim x 4 B into each rank per "
                     "launch: the whole-job value is the exchange's rate when that exceeds the kernel time (DESIGN.md §7)",
         }
-    if senv is not None and gather == "all" and world > 1 and not args.no_alt_modes:
+    if senv is not None and gather == "all" and world > 1 and args.alt_modes:
         # The same launches with the two lighter exchanges, outside the headline's timed region (K // 2 launches each,
         # same barrier / max-over-ranks protocol): what the sharded simulator does when not every observation has
-        # to cross xGMI.  Reported beside `value`, never instead of it.
+        # to cross xGMI.  Reported beside `value`, never instead of it.  Opt-in.  No new multi-GB allocation (the
+        # rollouts write into the headline's output blocks), and every phase ends with an all-reduced error flag, so
+        # that a rank that failed and the ranks that did not leave together instead of one of them blocking in a
+        # barrier the other never reaches.
         alt = {}
-        try:
-            for mode in ("final", "none"):
-                K2 = max(3, K // 2)
+        failed = False
+        for mode in ("final", "none"):
+            if failed:
+                break
+            err = None
+            e2 = torch.zeros(1, dtype=torch.float64, device=device)
+            K2 = max(3, K // 2)
+            try:
+                def alt_launch(k):
+                    out = senv.engine.rollout(act, out=outs[k & 1], **rkw)
+                    if mode == "final":
+                        senv.gather_final_async(out["obs"][-1])
                 for k in range(2):
-                    sharded_launch(k, mode)
+                    alt_launch(k)
                 drain()
-                torch.cuda.synchronize(device)
-                dist.barrier()
                 torch.cuda.synchronize(device)
                 t1 = time.perf_counter()
                 for k in range(K2):
-                    sharded_launch(k, mode)
+                    alt_launch(k)
                 drain()
                 torch.cuda.synchronize(device)
-                dist.barrier()
-                torch.cuda.synchronize(device)
-                e2 = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
-                dist.all_reduce(e2, op=dist.ReduceOp.MAX)
-                alt[mode] = {"value": float(world) * n * H * K2 / float(e2.item()), "steps": K2,
-                             "ms_per_step": float(e2.item()) / K2 * 1e3}
-        except Exception as e:   # noqa: BLE001 — the headline line must not be lost to the extras
-            alt["error"] = f"{type(e).__name__}: {e}"
+                e2[0] = time.perf_counter() - t1
+            except Exception as e:   # noqa: BLE001 — local failure: reported to every rank by the flag below
+                err = f"{type(e).__name__}: {e}"
+            flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)          # reached by every rank, failed or not
+            if float(flag.item()) > 0:
+                alt[mode] = {"error": err or "another rank failed"}
+                failed = True
+                continue
+            dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+            alt[mode] = {"value": float(world) * n * H * K2 / float(e2.item()), "steps": K2,
+                         "ms_per_step": float(e2.item()) / K2 * 1e3,
+                         "note": "wall time per rank from launch to drained exchange, max over ranks (no barrier inside)"}
         line["other_exchange_modes"] = alt
+
+    # Extras that run before the one JSON line is printed are bounded by a wall-clock limit: if they hang (a GPU fault
+    # in the probe, a collective that never completes) the watchdog prints the headline as it stands and ends the process.
+    emitted = {"done": False}
+
+    def emit_and_exit():
+        if rank == 0 and not emitted["done"]:
+            emitted["done"] = True
+            line.setdefault("extras_timed_out", True)
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    import threading
+    watchdog = threading.Timer(max(5.0, args.probe_seconds), emit_and_exit)
+    watchdog.daemon = True
+    watchdog.start()
+    if world == 1 and not args.no_secondary and not force_sharded and plan["config"] == 2:
+        if senv is None:       # give the headline's 6.7-GB output block back first
+            env.close()
+            env = None
+            torch.cuda.empty_cache()
+        line["secondary_kernels"] = secondary_kernels(device, n, H)
     if not args.no_sac_probe and not rehearsal and not force_sharded and (world == 1 or args.sac_probe):
         probe = sac_first_capture(device, world if senv is not None else 1, rank)   # every rank takes part (collectives)
         line["sac_first_capture"] = probe
+    watchdog.cancel()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_seconds)
     elif rank == 0:
         line["cpu_baseline"] = None
-    if rank == 0:
+    if rank == 0 and not emitted["done"]:
+        emitted["done"] = True
         print(json.dumps(line), flush=True)
     if senv is not None:
         senv.close()
         dist.destroy_process_group()
-    else:
+    elif env is not None:
         env.close()
 
 

@@ -221,6 +221,13 @@ int salp_vec_get_stats(salp_vec_t* h, salp_stats_t* out);
 int salp_vec_clear_stats(salp_vec_t* h);
 int64_t salp_vec_global_step(const salp_vec_t* h);
 
+/* Which kernel instantiation the handle's most recent step / rollout call ran (introspection for tests and profiles; no
+ * reference counterpart): info[0] food slots of the kernel (1, 4, 8, 12, 16), [1] observed-food capacity (3, or 8 = the
+ * generic instantiation), [2] 1 = the reference's constants compiled in as literals, [3] forced breathing, [4] 1 = the
+ * common output signature (obs, reward, terminated, truncated; no final_obs / info), [5] 1 = actions drawn in the kernel,
+ * [6] envs served by the unpredicated launch (whole wavefronts), [7] envs served by the predicated launch. */
+int salp_vec_last_launch(const salp_vec_t* h, int64_t info[8]);
+
 /* The curriculum's attribute poke `env.base_num_food_items = k` (src/salp/training/continuous_trainer.py:409-411;
  * src/salp/environments/salp_snake_env.py:36): the number of foods placed at every LATER reset of an env
  * (snake:144-148; with random_food_count the upper bound of the draw).  0 <= k <= the num_food_items the

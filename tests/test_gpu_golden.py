@@ -58,3 +58,33 @@ def test_hip_matches_reference_vectors(name):
     assert np.array_equal(np.isnan(f64), np.isnan(e))
     assert np.nanmax(np.abs(f64 - e)) <= 1e-9
     dev.close()
+
+
+@pytest.mark.parametrize("F", [4, 12, 16])
+def test_tie_order_in_whole_wavefronts_fused_rollout(F):
+    """The tie-order vectors (tests/golden/gen_golden.py `tie_order_f*`: exact ties, squared distances a few ulp apart,
+    a pair only fp64 can tell apart) through the UNPREDICATED fused rollout kernels: the five envs tiled 64 times into
+    320 envs = five whole wavefronts, 130 steps in one launch (the swimmers rest until step ~135, so every copy sees the
+    injected geometry; the copies differ from the vector only through their draw streams, which nothing uses before the
+    first thrust).  F = 4: foods in VGPRs (4 slots); 12: the sac_gail kernel; 16: foods in LDS."""
+    z, meta, cfg = load_fixture(f"tie_order_f{F}")
+    reps, H = 64, 130
+    n0 = z["actions"].shape[1]
+    n = n0 * reps
+    dev = SalpLib(cfg, n, device_id=0, seed=meta["seed"], env_index_base=meta["env_index_base"])
+    dev.set_state(np.ascontiguousarray(np.tile(z["inject_f64"], (1, reps))), np.ascontiguousarray(np.tile(z["inject_i32"], (1, reps))), 0)
+    act = np.ascontiguousarray(np.tile(z["actions"][:H], (1, reps, 1)))
+    obs = np.empty((H, n, cfg.obs_dim), np.float32)
+    rew = np.empty((H, n), np.float32)
+    term = np.empty((H, n), np.uint8)
+    trunc = np.empty((H, n), np.uint8)
+    dev.rollout(act, H, obs, rew, term, trunc, None, None, 0)
+    ll = dev.last_launch()
+    assert ll["envs_unpredicated"] == n and ll["envs_predicated"] == 0 and ll["full_signature"] == 1
+    assert ll["food_slots"] == {4: 4, 12: 12, 16: 16}[F]
+    want = np.tile(z["obs"][:H], (1, reps, 1))
+    assert obs_diff(cfg, obs, want).max() <= 1e-5
+    r = np.tile(z["reward"][:H], (1, reps))
+    assert (np.abs(rew - r) / np.maximum(1.0, np.abs(r))).max() <= 1e-5
+    assert not term.any() and not trunc.any()
+    dev.close()

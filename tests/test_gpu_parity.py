@@ -95,6 +95,19 @@ CASES = {
     "K0_no_food_obs": dict(preset="single_food", max_observed_food=0),
     "F0_empty": dict(preset="single_food", num_food_items=0),
     "short_timeout": dict(preset="single_food", max_steps_without_food=40),
+    # the unpredicated (main-launch) forms of the instantiations that only ran predicated before round 3:
+    "F16_lds_foods": dict(preset="sac_gail", num_food_items=16, max_steps_without_food=200),           # <16, 3, STD>: foods in LDS
+    "F16_lds_foods_other_tank": dict(preset="sac_gail", num_food_items=16, width=900, height=650),      # <16, 3, !STD>
+    "F14_K5_generic_lds": dict(preset="sac_gail", num_food_items=14, max_observed_food=5),              # <16, 8>: generic, foods in LDS
+    "F9_K5_generic_reg": dict(preset="sac_gail", num_food_items=9, max_observed_food=5),                # <12, 8>: generic, foods in VGPRs
+    "F3_other_tank": dict(preset="sac_gail", num_food_items=3, width=900, tank_margin=40.0),            # <4, 3, !STD>
+}
+# (food slots, observed capacity, literal constants) of the kernel each case must run (salp_vec_last_launch)
+EXPECT_KERNEL = {
+    "single_food": (1, 3, 1), "sac_gail_F12": (12, 3, 1), "class_default_F5": (8, 3, 1), "no_respawn_F3": (4, 3, 1),
+    "other_tank_F1": (1, 3, 0), "other_physics_F12": (12, 3, 0), "K2_generic": (12, 8, 0),
+    "F16_lds_foods": (16, 3, 1), "F16_lds_foods_other_tank": (16, 3, 0), "F14_K5_generic_lds": (16, 8, 0),
+    "F9_K5_generic_reg": (12, 8, 0), "F3_other_tank": (4, 3, 0),
 }
 
 
@@ -131,7 +144,30 @@ def test_rollout_parity(name):
     assert st["env_steps"] == n * H
     assert st["episodes"] == int(done.sum())
     assert st["terminated"] == int(ref["terminated"].sum()) and st["truncated"] == int(ref["truncated"].sum())
-    print(f"{name}: max obs diff {dmax:.3g}, max rel reward diff {rmax:.3g}, episodes {st['episodes']}")
+    ll = dev.last_launch()      # 2048 envs = 32 whole wavefronts: the unpredicated kernel, non-FULL signature (final_obs)
+    assert ll["envs_unpredicated"] == n and ll["envs_predicated"] == 0 and ll["full_signature"] == 0
+    if name in EXPECT_KERNEL:
+        assert (ll["food_slots"], ll["observed_capacity"], ll["literal_constants"]) == EXPECT_KERNEL[name], ll
+    print(f"{name}: max obs diff {dmax:.3g}, max rel reward diff {rmax:.3g}, episodes {st['episodes']}, kernel {ll}")
+    dev.close()
+
+
+@pytest.mark.parametrize("foods,slots", [(3, 4), (5, 8), (12, 12), (16, 16)])
+def test_multi_food_full_signature_main_launch(foods, slots):
+    """The FULL-signature unpredicated kernels (what bench.py and salp_vec_rollout without final_obs run) of every
+    multi-food slot count, with captures, respawns and truncation resets inside whole wavefronts."""
+    cfg = pkg.load_env_config("sac_gail", num_food_items=foods, max_steps_without_food=120)
+    n, H, seed = 1024, 400, 31 + foods
+    act = make_actions(cfg, H, n, seed=foods)
+    got, dev = run_device(cfg, n, act, seed=seed)
+    orc = ol.OracleVec(cfg, n, seed=seed)
+    ref = orc.rollout(act)
+    assert_parity(cfg, got, ref, f"F{foods} full signature")
+    assert_state_parity(cfg, dev, orc, f"F{foods} full signature")
+    ll = dev.last_launch()
+    assert ll["food_slots"] == slots and ll["observed_capacity"] == 3 and ll["literal_constants"] == 1
+    assert ll["full_signature"] == 1 and ll["envs_unpredicated"] == n and ll["envs_predicated"] == 0
+    assert dev.stats()["truncated"] > 100
     dev.close()
 
 
@@ -360,15 +396,23 @@ def _random_cfg(rng):
 def test_random_configuration_parity(case):
     rng = np.random.default_rng(1000 + case)
     cfg = _random_cfg(rng)
-    n, H, seed = 777, 260, int(rng.integers(0, 2 ** 31))          # ragged last wavefront
+    # 20 cases of 777 envs: a small ragged batch (n H <= 2^22) runs ONE predicated launch over the whole range
+    # (launch_rollout), so these exercise the RAGGED = true kernels only, with final_obs (non-FULL signature).
+    # Cases 5, 11, 17, 23: 16449 envs x 260 steps (n H > 2^22) split into the unpredicated main launch over 257 whole
+    # wavefronts plus a one-env predicated launch, FULL signature.
+    big = case % 6 == 5
+    n, H, seed = (16449 if big else 777), 260, int(rng.integers(0, 2 ** 31))
     act = make_actions(cfg, H, n, seed=case, scale=1.2)            # a little outside the Box too
-    got, dev = run_device(cfg, n, act, seed=seed, want_final=True)
-    orc = ol.OracleVec(cfg, n, seed=seed)
-    ref = orc.rollout(act, want_final=True)
+    got, dev = run_device(cfg, n, act, seed=seed, want_final=not big)
+    orc = ol.OracleVec(cfg, n, seed=seed, threads=8 if big else 1)
+    ref = orc.rollout(act, want_final=not big)
     assert_parity(cfg, got, ref, f"random case {case}: {cfg}")
     assert_state_parity(cfg, dev, orc, f"random case {case}")
-    done = (ref["terminated"] | ref["truncated"]).astype(bool)
-    if done.any():
-        assert obs_diff(cfg, got["final_obs"][done], ref["final_obs"][done]).max() <= OBS_TOL
+    ll = dev.last_launch()
+    assert (ll["envs_unpredicated"], ll["envs_predicated"]) == ((16448, 1) if big else (0, 777)), ll
+    if not big:
+        done = (ref["terminated"] | ref["truncated"]).astype(bool)
+        if done.any():
+            assert obs_diff(cfg, got["final_obs"][done], ref["final_obs"][done]).max() <= OBS_TOL
     dev.close()
     orc.close()

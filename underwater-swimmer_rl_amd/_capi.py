@@ -28,7 +28,7 @@ EXPORTS = (
     "salp_vec_num_food", "salp_vec_device", "salp_vec_reset", "salp_vec_step", "salp_vec_rollout",
     "salp_vec_observe", "salp_vec_get_state", "salp_vec_set_state", "salp_vec_get_stats",
     "salp_vec_clear_stats", "salp_vec_global_step", "salp_vec_set_base_num_food", "salp_vec_base_num_food",
-    "salp_vec_reseed",
+    "salp_vec_reseed", "salp_vec_last_launch",
 )
 
 
@@ -88,6 +88,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.salp_vec_set_state.argtypes = [vp, vp, vp, u32, vp]
     L.salp_vec_get_stats.argtypes = [vp, ctypes.POINTER(CStats)]
     L.salp_vec_clear_stats.argtypes = [vp]
+    if path is None or hasattr(L, "salp_vec_last_launch"):
+        L.salp_vec_last_launch.argtypes = [vp, ctypes.POINTER(ctypes.c_int64)]
     if path is None or hasattr(L, "salp_vec_reseed"):   # (an explicit path may be an older A/B variant, profiles/ab_bench.py)
         L.salp_vec_reseed.argtypes = [vp, u64, vp, u32, vp]
     L.salp_vec_global_step.argtypes = [vp]
@@ -183,6 +185,14 @@ class SalpLib:
         s = CStats()
         check(self.lib, self.lib.salp_vec_get_stats(self._h, ctypes.byref(s)), "salp_vec_get_stats")
         return {k: getattr(s, k) for k, _ in CStats._fields_}
+
+    def last_launch(self) -> dict:
+        """The kernel instantiation of the most recent step / rollout call (salp_vec_last_launch)."""
+        a = (ctypes.c_int64 * 8)()
+        check(self.lib, self.lib.salp_vec_last_launch(self._h, a), "salp_vec_last_launch")
+        keys = ("food_slots", "observed_capacity", "literal_constants", "forced", "full_signature", "actions_in_kernel",
+                "envs_unpredicated", "envs_predicated")
+        return dict(zip(keys, (int(v) for v in a)))
 
     def clear_stats(self):
         check(self.lib, self.lib.salp_vec_clear_stats(self._h), "salp_vec_clear_stats")

@@ -643,6 +643,7 @@ struct salp_vec {
   size_t act_bytes;
   size_t nf_rows;
   hipStream_t last_stream;   // the stream of the handle's most recent launch: what get_stats / destroy wait for
+  int64_t last_launch[8];    // salp_vec_last_launch
 };
 
 namespace {
@@ -799,6 +800,9 @@ int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
   // A small ragged batch (step-per-launch acting loops) is launch-bound: one predicated launch over the whole
   // range instead of two; the predicates only cost when the write stream is the bound.
   if (n_full < h->n && h->n * (int64_t)H <= (int64_t)1 << 22) n_full = 0;
+  h->last_launch[0] = h->fmax; h->last_launch[1] = h->kmax; h->last_launch[2] = (h->kmax == 3) ? h->std_consts : 0;
+  h->last_launch[3] = h->P.forced; h->last_launch[4] = full; h->last_launch[5] = gen;
+  h->last_launch[6] = n_full; h->last_launch[7] = h->n - n_full;
   if (n_full > 0) {
     const unsigned grid = (unsigned)((n_full + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(rollout_kernel_for<false>(h, full, gen), dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
@@ -944,6 +948,11 @@ int salp_exp_read_counters(unsigned long long* dst) {
 int salp_vec_num_food(const salp_vec_t* h) { return h ? h->F : 0; }
 int salp_vec_device(const salp_vec_t* h) { return h ? h->device : -1; }
 int64_t salp_vec_global_step(const salp_vec_t* h) { return h ? h->global_step : 0; }
+int salp_vec_last_launch(const salp_vec_t* h, int64_t info[8]) {
+  if (!h || !info) return fail(SALP_ERR_INVALID, "handle/info is NULL");
+  memcpy(info, h->last_launch, sizeof(h->last_launch));
+  return SALP_OK;
+}
 
 int salp_vec_set_base_num_food(salp_vec_t* h, int32_t k) {
   if (!h) return fail(SALP_ERR_INVALID, "handle is NULL");

@@ -32,18 +32,25 @@ def _to_tensor(x, device):
 class ShardedSalpVectorEnv:
     def __init__(self, config="single_food", num_envs: int = 8 * 131072, *, process_group=None,
                  device: Optional[str] = None, seed: int = 0, engine_factory: Optional[Callable] = None,
-                 gather_final_observation: bool = True, **overrides):
+                 gather_final_observation: bool = True, rehearse_shard: Optional[tuple] = None, **overrides):
+        """rehearse_shard=(r, G): simulate shard r of a G-way split of `num_envs` on THIS process whatever its rank
+        (envs [r N/G, (r+1) N/G), same global-index draw keys), with the collectives running over the real group — how a
+        one-GPU box runs the per-GPU workload of a larger job (tests/test_gpu_sharded_workload.py: BASELINE configs[3],
+        shard 7 of 8).  A real job never passes it."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend 'nccl' on GPUs)")
         self.pg = process_group
         self.rank = dist.get_rank(self.pg)
         self.world = dist.get_world_size(self.pg)
-        if num_envs % self.world != 0:
-            raise ValueError(f"num_envs={num_envs} must be divisible by world size {self.world}")
+        shard, shards = (self.rank, self.world) if rehearse_shard is None else (int(rehearse_shard[0]), int(rehearse_shard[1]))
+        if not 0 <= shard < shards:
+            raise ValueError(f"rehearse_shard={rehearse_shard}: shard index out of range")
+        if num_envs % shards != 0:
+            raise ValueError(f"num_envs={num_envs} must be divisible by the number of shards {shards}")
         self.cfg = _as_config(config, **overrides)
         self.num_envs = int(num_envs)
-        self.local_envs = self.num_envs // self.world
-        self.env_index_base = self.rank * self.local_envs
+        self.local_envs = self.num_envs // shards
+        self.env_index_base = shard * self.local_envs
         if engine_factory is None:
             dev = device or f"cuda:{torch.cuda.current_device()}"
             self.engine = SalpVectorEnv(self.cfg, self.local_envs, device=dev, seed=seed,
