@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--log-every", type=int, default=200)
     ap.add_argument("--eager", action="store_true", help="issue every kernel from Python (train_sac) instead of "
                     "one hipGraph replay per vector step (train_sac_graphed)")
+    ap.add_argument("--graphed", action="store_true", help="under torchrun (more than one rank): use the segmented hipGraph form "
+                    "(graph segments + RCCL gradient all-reduces between the replays).  The multi-rank default is --eager until that "
+                    "form has run on two real GPUs (it is covered by gloo and world-size-1 tests only)")
     args = ap.parse_args()
     import torch
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -40,6 +43,8 @@ def main():
     cfg.learning_starts, cfg.updates_per_step = args.learning_starts, args.updates_per_step
     agent = SAC(env.obs_dim, env.act_dim, cfg, device=dev, seed=0, data_parallel=world > 1,
                 act_low=env.single_action_space.low, act_high=env.single_action_space.high)
+    if world > 1 and not args.graphed:
+        args.eager = True
     if args.eager:
         m = train_sac(env, agent, args.steps, log_every=args.log_every, stop_at_first_food=args.stop_at_first_food)
     else:

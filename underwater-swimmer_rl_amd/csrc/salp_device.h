@@ -759,8 +759,8 @@ __device__ __forceinline__ void step_tail(EnvCore& e, const DevParams& P, StepOu
 }
 
 template <int FMAX, bool FORCED, bool STD>
-__device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, uint64_t genv, float a0, float a1) {
-  const double r = step_head<FORCED, STD>(e, P, genv, a0, a1);
+__device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, uint64_t genv, float a0, float a1 SALP_STAMP_PARAM) {
+  const double r = step_head<FORCED, STD>(e, P, genv, a0, a1 SALP_STAMP_PASS);
   StepOut o;
   o.rmax = r;
   // snake:204-217 _check_food_collection (first live food inside the capture radius)
@@ -810,6 +810,7 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
     for (int k = 0; k < FMAX; ++k) any_alive = any_alive || !is_none(e.fx[k]);
   }
   step_tail(e, P, o, rew, any_alive);
+  SALP_STAMP(5);
   return o;
 }
 

@@ -257,7 +257,14 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, ff, mir, dist_col, P, genv, c0, c1, K, fq, nlive, order_cache, &cold->P);
 #endif
     }
-    else o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
+    else {
+#ifdef SALP_EXP_STAMPS
+      { StampAcc* stamps_ = &stamps; SALP_STAMP(0); }
+      o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1, &stamps);
+#else
+      o = step_env<FMAX, FORCED, STD>(e, P, genv, c0, c1);
+#endif
+    }
 #endif
     const bool done = o.terminated || o.truncated;
     double rmax = o.rmax;

@@ -210,6 +210,7 @@ class SAC:
         self.updates = 0
         self.world = 1
         self.exchange = False      # gradients go through the flat exchange buffers (world > 1, or forced by a test)
+        self.keep_grads = False    # zero the .grad tensors in place instead of dropping them (segmented graphs, see train_sac_graphed)
         if self.data_parallel:
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -278,7 +279,7 @@ class SAC:
             target = rew + self.cfg.gamma * (1.0 - term) * (torch.min(tq1, tq2) - alpha * nlogp)
         q1, q2 = self.critic(obs, act)
         critic_loss = 0.5 * (F.mse_loss(q1, target) + F.mse_loss(q2, target))
-        self.critic_opt.zero_grad(set_to_none=True)
+        self.critic_opt.zero_grad(set_to_none=not self.keep_grads)
         critic_loss.backward()
         self._carry_set(obs=obs, critic_loss=critic_loss)
         if self.exchange:
@@ -296,11 +297,11 @@ class SAC:
         pa, logp = self.actor(obs)
         pq1, pq2 = self.critic(obs, pa)
         actor_loss = (alpha * logp - torch.min(pq1, pq2)).mean()
-        self.actor_opt.zero_grad(set_to_none=True)
+        self.actor_opt.zero_grad(set_to_none=not self.keep_grads)
         actor_loss.backward()
         if self.learn_alpha:
             alpha_loss = -(self.log_alpha * (logp.detach() + self.target_entropy).mean())
-            self.alpha_opt.zero_grad(set_to_none=True)
+            self.alpha_opt.zero_grad(set_to_none=not self.keep_grads)
             alpha_loss.backward()
         self._carry_set(actor_loss=actor_loss, entropy=-logp.detach().mean())
         if self.exchange:
@@ -439,7 +440,18 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
     if dev.type != "cuda":
         raise RuntimeError("train_sac_graphed needs a ROCm device")
     segmented = agent.world > 1 or force_segments
+    saved_mode = (agent.exchange, agent.keep_grads)
     agent.exchange = segmented
+    try:
+        return _train_sac_graphed(env, agent, total_vector_steps, buffer, reward_fn, stop_at_first_food, poll_every,
+                                  warmup_iters, segmented)
+    finally:
+        agent.exchange, agent.keep_grads = saved_mode     # the agent leaves as it came (round 2 left exchange switched on)
+
+
+def _train_sac_graphed(env, agent, total_vector_steps, buffer, reward_fn, stop_at_first_food, poll_every, warmup_iters,
+                       segmented) -> Dict[str, float]:
+    cfg, dev = agent.cfg, agent.device
     n = env.num_envs
     buffer = buffer or DeviceReplayBuffer(cfg.buffer_size, env.obs_dim, env.act_dim, dev)
     low = torch.as_tensor(env.single_action_space.low, device=dev)
@@ -559,6 +571,12 @@ def train_sac_graphed(env, agent: SAC, total_vector_steps: int, buffer: Optional
             warm[key] = warm.get(key, 0) + 1
         else:
             torch.cuda.synchronize(dev)
+            if segmented and learn:
+                # Segments of one iteration read and write the same .grad tensors (backward in one, _unpack / optimiser
+                # step in the next).  Keep the tensors the eager warm-up iterations allocated (ordinary memory, stable
+                # addresses) and zero them in place, instead of letting the first captured backward allocate them in the
+                # graph pool, where their lifetime across segments rested on replay order alone.
+                agent.keep_grads = True
             graphs[key] = capture(plan(random_actions, learn))      # capture runs no kernel
             continue
         step += 1
