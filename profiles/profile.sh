@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BARGS="--no-cpu-baseline --no-sac-probe $@"
+BARGS="--no-cpu-baseline --no-sac-probe --no-secondary $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 10 --warmup 2 $BARGS > $OUT/bench_kt.json 2> $OUT/kt.err
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 4 --warmup 1 $BARGS > /dev/null 2> $OUT/$name.err; }
 pass pmc_fetch FETCH_SIZE

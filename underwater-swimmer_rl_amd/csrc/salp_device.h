@@ -556,38 +556,48 @@ __device__ __forceinline__ Nearest nearest_food(const Env<FMAX>& e) {
   return g;
 }
 
-// fp32 helpers for quantities that only leave the simulator (observation angle, reward shaping).
-// atan2 for the food bearing: t = min/max via v_rcp_f32 + one Newton step, odd minimax polynomial
-// of degree 17 on [0, 1] (max error ~1e-7 rad), then octant / quadrant unfolding.
+// fp32 helpers for quantities that only leave the simulator (observation angle, reward shaping).  Three food bearings per
+// step were 110 of the 12-food kernel's ~590 VALU instructions per wavefront-step (round 2: degree-17 polynomial, Newton
+// step on the reciprocal, compare / select unfolding and wrapping); the contract is 1e-5 on angle / pi.
+// atan2 for the food bearing: t = min / max through v_rcp_f32 (1 ulp), odd minimax polynomial on [0, 1] (Remez fits),
+// octant / quadrant unfolding, sign by bit copy.  PRECISE = false (bearings that only go to the observation): degree 11,
+// max error 1.7e-6 rad = 5.3e-7 of the observation's unit.  PRECISE = true (the nearest food's bearing, which the reward
+// multiplies by proximity_reward_weight, 5 in single_food.yaml): degree 13, 2.5e-7 rad.
+template <bool PRECISE>
 __device__ __forceinline__ float atan2_fast(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
-  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-  float r = __builtin_amdgcn_rcpf(mx);
-  r = fmaf(fmaf(-mx, r, 1.0f), r, r);           // Newton: r <- r + r(1 - mx r)
-  float t = mn * r;
-  if (!(mx > 0.0f)) t = 0.0f;                    // atan2(0, 0) = 0 (math.atan2 convention)
+  const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1.0e-30f);   // v_max3_f32; atan2(0, 0) = 0 (math.atan2): t = 0 * 1e30
+  const float mn = __builtin_fminf(ax, ay);
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
   const float z = t * t;
-  float p = fmaf(z, 0.0028662257f, -0.0161657367f);
-  p = fmaf(z, p, 0.0429096138f);
-  p = fmaf(z, p, -0.0752896400f);
-  p = fmaf(z, p, 0.1065626393f);
-  p = fmaf(z, p, -0.1420889944f);
-  p = fmaf(z, p, 0.1999355085f);
-  p = fmaf(z, p, -0.3333314528f);
-  float a = fmaf(t * z, p, t);
+  float p;
+  if (PRECISE) {
+    p = fmaf(z, 0.006811792962253094f, -0.0336042195558548f);
+    p = fmaf(z, p, 0.07962366938591003f);
+    p = fmaf(z, p, -0.1323334276676178f);
+    p = fmaf(z, p, 0.19807815551757812f);
+    p = fmaf(z, p, -0.3331736922264099f);
+    p = fmaf(z, p, 0.9999961256980896f);
+  } else {
+    p = fmaf(z, -0.01171913556754589f, 0.05264735221862793f);
+    p = fmaf(z, p, -0.116426482796669f);
+    p = fmaf(z, p, 0.19354037940502167f);
+    p = fmaf(z, p, -0.33262282609939575f);
+    p = fmaf(z, p, 0.9999772310256958f);
+  }
+  float a = t * p;
   if (ay > ax) a = 1.57079632679489662f - a;
   if (x < 0.0f) a = 3.14159265358979324f - a;
-  return (y < 0.0f) ? -a : a;
+  return __builtin_copysignf(a, y);
 }
 
-// cos(x) for |x| <= pi (a wrapped heading): fold to [0, pi/2], even Taylor polynomial to x^14.
+// cos(x) for |x| <= pi (a wrapped heading): fold to [0, pi/2], even Taylor polynomial to x^12 (error 6.5e-9).
 __device__ __forceinline__ float cos_wrapped(float x) {
   float ax = fabsf(x);
   const bool flip = ax > 1.57079632679489662f;
   if (flip) ax = 3.14159265358979324f - ax;
   const float z = ax * ax;
-  float p = fmaf(z, -1.1470745597729725e-11f, 2.08767569878681e-09f);
-  p = fmaf(z, p, -2.755731922398589e-07f);
+  float p = fmaf(z, 2.08767569878681e-09f, -2.755731922398589e-07f);
   p = fmaf(z, p, 2.48015873015873e-05f);
   p = fmaf(z, p, -1.3888888888888889e-03f);
   p = fmaf(z, p, 4.1666666666666664e-02f);
@@ -596,12 +606,12 @@ __device__ __forceinline__ float cos_wrapped(float x) {
   return flip ? -c : c;
 }
 
-// Heading of a food relative to the body axis, wrapped to [-pi, pi] (fp32).
+// Heading of a food relative to the body axis, wrapped to [-pi, pi] (fp32): both angles are in [-pi, pi], so one multiple
+// of 2 pi at most is off — round-to-nearest-even of rel / 2 pi is 0 on the closed interval, as snake:403-407's strict loops.
+template <bool PRECISE = false>
 __device__ __forceinline__ float relative_heading(float dy, float dx, float th) {
-  float rel = atan2_fast(dy, dx) - th;
-  if (rel > 3.14159265358979f) rel -= 6.28318530717959f;
-  if (rel < -3.14159265358979f) rel += 6.28318530717959f;
-  return rel;
+  const float rel = atan2_fast<PRECISE>(dy, dx) - th;
+  return fmaf(__builtin_rintf(rel * 0.15915494309189535f), -6.28318530717959f, rel);
 }
 
 struct StepOut {
@@ -798,7 +808,7 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
     if (g.any) {
       // alignment = cos(wrap(atan2(dy,dx) - theta)); fp32 is enough for a term that only leaves
       // the simulator (snake:301-322).  The heading is handed to observe() for reuse.
-      o.rel = relative_heading((float)g.dy, (float)g.dx, (float)e.th);
+      o.rel = relative_heading<true>((float)g.dy, (float)g.dx, (float)e.th);
       o.rel_valid = true;
       rew += P.prox_w * (double)cos_wrapped(o.rel);
     }

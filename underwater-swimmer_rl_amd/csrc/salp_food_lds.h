@@ -213,7 +213,7 @@ __device__ __forceinline__ StepOut step_env_lds(EnvCore& e, const FoodLds& f, co
     if (P.efficiency_bonus > 0) rew += P.efficiency_bonus * (double)(P.max_steps_wo_food - e.ssf);
   }
   if (o.collision) rew += P.collision_penalty;
-  o.rel = relative_heading(q.by[0], q.bx[0], (float)e.th);
+  o.rel = relative_heading<true>(q.by[0], q.bx[0], (float)e.th);
   o.rel_valid = q.idx[0] >= 0;
   if (P.prox_w > 0) {
     const double al = P.prox_w * (double)cos_wrapped(o.rel);

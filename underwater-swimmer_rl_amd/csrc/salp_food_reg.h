@@ -399,7 +399,7 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, KMAX
     const double pen = cold->collision_penalty;
     rew = o.collision ? rew + pen : rew;
   }
-  o.rel = relative_heading(q.by[0], q.bx[0], (float)e.th);
+  o.rel = relative_heading<true>(q.by[0], q.bx[0], (float)e.th);
   o.rel_valid = q.idx[0] >= 0;
   if (P.prox_w > 0) {
     const double al = P.prox_w * (double)cos_wrapped(o.rel);
@@ -439,6 +439,7 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, FoodF32<FMAX, 
     int todo_l = __builtin_amdgcn_readlane(todo, L);
     const int limit_l = __builtin_amdgcn_readlane(limit, L);
     uint32_t empty = (uint32_t)__builtin_amdgcn_readlane((int)my_empty, L);
+    uint32_t present = ~empty & ((1u << P.F) - 1u);   // slots of env L that hold a food: only those can reject a candidate
     uint32_t consumed = 0;                         // draws of env L's stream used so far
     int attempts = 0;
     while (todo_l > 0) {
@@ -453,10 +454,10 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, FoodF32<FMAX, 
       }
 #pragma unroll
       for (int k = 0; k < FMAX; ++k) {
-        if (k < P.F) {                             // wave-uniform
+        if ((present >> k) & 1u) {                 // wave-uniform; an autoreset starts with every slot empty: no test at all
           const double fxk = bcast_lane(e.fx[k], L), fyk = bcast_lane(e.fy[k], L);
           const double dx = x - fxk, dy = y - fyk;
-          ok = ok && !(dx * dx + dy * dy < min2);  // NaN (empty) slots never reject
+          ok = ok && !(dx * dx + dy * dy < min2);
         }
       }
       int j = 0;                                   // first candidate of this batch not yet judged
@@ -483,6 +484,7 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, FoodF32<FMAX, 
         j = a + 1;
       }
       consumed += (uint32_t)j;
+      present |= filled;
       if (filled) {                                // wave-uniform: lane L takes this batch's points (a later batch tests against them)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
