@@ -416,3 +416,57 @@ def test_random_configuration_parity(case):
             assert obs_diff(cfg, got["final_obs"][done], ref["final_obs"][done]).max() <= OBS_TOL
     dev.close()
     orc.close()
+
+
+@pytest.mark.parametrize("foods", [4, 12, 16])
+def test_near_tie_food_order_matches_oracle_across_scales(foods):
+    """The order of the observed foods when two of them are ALMOST equally far — relative distance gaps from 1e-16 to
+    1e-4, at distances 60..200 px — must be the reference's (stable sort on the fp64 distance,
+    snake:382).  The fp32 ordering pass (csrc/salp_food_reg.h) may only decide where its error bound separates the keys
+    and must fall back to the exact order otherwise; the LDS-food path (16 foods) likewise at its 2^-44 bound.  A wrong
+    bound would show as two swapped food blocks (bearing columns differ by O(1)).  4096 resting swimmers (zero velocity:
+    the geometry holds for the whole rollout), observe() and 20 fused steps."""
+    cfg = pkg.load_env_config("sac_gail", num_food_items=foods, proximity_reward_weight=1.0)
+    n, H, seed = 4096, 20, 77
+    dev = SalpLib(cfg, n, device_id=0, seed=seed)
+    orc = ol.OracleVec(cfg, n, seed=seed, threads=8)
+    f64, i32 = get_state(dev, cfg)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(380, 420, n); y = rng.uniform(280, 320, n)
+    f64[_capi.F_X], f64[_capi.F_Y] = x, y
+    f64[_capi.F_VX] = f64[_capi.F_VY] = f64[_capi.F_OMEGA] = 0.0
+    f64[_capi.F_THETA] = rng.uniform(-3, 3, n)
+    F = foods
+    # every food far away first, all distinct
+    for k in range(F):
+        ang = rng.uniform(0, 2 * np.pi, n)
+        rad = rng.uniform(215, 235, n) + 0.37 * k
+        f64[_capi.F_FOOD0 + k] = x + rad * np.cos(ang)
+        f64[_capi.F_FOOD0 + F + k] = y + 0.85 * rad * np.sin(ang)
+    # two (sometimes three) slots, in random slot order, at nearly the same distance d in [45, 200]
+    d = rng.uniform(60, 200, n)                       # outside the capture radius (<= 54 px)
+    gap = 10.0 ** rng.uniform(-16, -4, n) * rng.choice([-1.0, 1.0], n)
+    slots = np.argsort(rng.random((n, F)), axis=1)[:, :3]
+    angs = rng.uniform(0, 2 * np.pi, (n, 3))
+    dist = np.stack([d, d * (1.0 + gap), np.where(rng.random(n) < 0.3, d * (1.0 - 0.5 * gap), d + 60.0)], axis=1)
+    for j in range(3):
+        f64[_capi.F_FOOD0 + slots[:, j], np.arange(n)] = x + dist[:, j] * np.cos(angs[:, j])
+        f64[_capi.F_FOOD0 + F + slots[:, j], np.arange(n)] = y + dist[:, j] * np.sin(angs[:, j])
+    i32[_capi.I_STEPS_SINCE_FOOD] = 0
+    dev.set_state(f64, i32, 0)
+    fo, _ = orc.get_state()
+    fo[:] = f64
+    fo[_capi.F_ELLIPSE_A] = 30.0
+    fo[_capi.F_ELLIPSE_B] = 30.0
+    orc.set_state(fo, i32)
+    obs = np.empty((n, cfg.obs_dim), np.float32)
+    dev.observe(obs, 0)
+    d0 = obs_diff(cfg, obs, orc.observe())
+    assert d0.max() <= OBS_TOL, f"observe(): {d0.max()} at {np.unravel_index(d0.argmax(), d0.shape)}"
+    act = np.zeros((H, n, 1), np.float32)
+    got, _ = run_device(cfg, n, act, dev=dev)
+    ref = orc.rollout(act)
+    assert_parity(cfg, got, ref, f"near ties, {foods} foods")
+    assert dev.last_launch()["food_slots"] == {4: 4, 12: 12, 16: 16}[foods]
+    dev.close()
+    orc.close()
