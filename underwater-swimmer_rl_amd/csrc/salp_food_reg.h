@@ -356,8 +356,16 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, KMAX
       if (__any(o.collected)) {
         clear_slot(e, ff, m, o.collected, hit_k);
         all_live = false;
-        // the reward's nearest food and the observation are taken after the slot is cleared (snake:171-189, 301)
-        scan_foods_f32<FMAX, KMAX, false, false>(ff, m, Ksel, xf, yf, tol_c0, q, cnt_);
+        // The reward's nearest food is taken after the slot is cleared (snake:171-189, 301): with the captured food gone
+        // the nearest is the old nearest, or the old second if the captured one WAS the nearest — no second pass over the
+        // slots (240 instructions on ~7 % of the wavefront-steps).  The rest of the selection (entries 1.., the distance
+        // sum, the live count) is stale for these lanes and is not read: a capture always sends the wavefront through the
+        // rare region below, which selects again for the observation once the respawn has been placed.
+        {
+          const bool was_first = (int)(q.top[0] & 15u) == hit_k;
+          const uint32_t k0 = was_first ? q.top[1] : q.top[0];
+          q.idx[0] = o.collected ? ((k0 < kKeyInf) ? (int)(k0 & 15u) : -1) : q.idx[0];
+        }
         const DevParams& C = *cold;
         double bonus = C.food_reward;
         if (C.efficiency_bonus > 0) bonus += C.efficiency_bonus * (double)(C.max_steps_wo_food - e.ssf);
