@@ -36,6 +36,12 @@ struct MirrorLds {
   __device__ __forceinline__ void clear(int k) const { col[k * kFoodLanes] = make_float2(__builtin_nanf(""), __builtin_nanf("")); }
 };
 
+// Which instantiations keep the fp32 roundings in registers as well: the K = 3 kernels with 4 and 12 slots.  The 8-slot
+// kernel (5..8 foods) reads the mirror instead: with the copies it needs 133 VGPRs, without them 117 — under the 128 that
+// four wavefronts per SIMD allow, which its 40960 B of LDS per workgroup (exactly a quarter of the CU's) also do
+// (profiles/r03/ab_notes.md session 9); the 12-slot kernel is at three either way (49 KB) and gains 2.7 % from the copies.
+constexpr bool food_in_registers(int fmax, int kmax) { return kmax == 3 && fmax != 8; }
+
 // What the per-step pass reads (static slot index).  INREG (the K = 3 kernels): the mirror's values also in registers —
 // the pass then issues no LDS read at all (with six ds_read2st64_b64 and their waits in the pass the kernel ran 8 % slower
 // than round 2's, profiles/r03/ab_notes.md).  !INREG (the generic instantiation, already at its register limit): the pass
@@ -152,7 +158,7 @@ __device__ __forceinline__ void select_keys(const uint32_t (&key)[FMAX], uint32_
 // ALLLIVE: every slot of every lane holds a food (the steady state with respawn): no NaN can occur, the NaN guard of
 // the distance sum and the found tests are dropped.
 template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT>
-__device__ __forceinline__ void scan_foods_f32(const FoodF32<FMAX, KMAX == 3>& ff, const MirrorLds& m, int K, float xf, float yf, float tol_c0,
+__device__ __forceinline__ void scan_foods_f32(const FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, int K, float xf, float yf, float tol_c0,
                                                FoodScan<KMAX>& q, int& cnt) {
   uint32_t key[FMAX];
   float dsum = 0.f;
@@ -284,7 +290,7 @@ __device__ __forceinline__ void resolve_f32(const MirrorLds& m, int K, float xf,
 // Selection of the current food set around the current pose: pass, exact order where needed, geometry.
 // `dist`: see exact_order_reg.
 template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT>
-__device__ __forceinline__ void select_foods_reg(const Env<FMAX>& e, const FoodF32<FMAX, KMAX == 3>& ff, const MirrorLds& m, double* dist, int K,
+__device__ __forceinline__ void select_foods_reg(const Env<FMAX>& e, const FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, double* dist, int K,
                                                  float tol_c0, FoodScan<KMAX>& q, int& cnt) {
   const float xf = (float)e.x, yf = (float)e.y;
   scan_foods_f32<FMAX, KMAX, ALLLIVE, COUNT>(ff, m, K, xf, yf, tol_c0, q, cnt);
@@ -326,7 +332,7 @@ __device__ __forceinline__ void clear_slot(Env<FMAX>& e, FoodF32<FMAX, INREG>& f
 
 // One reference step of a multi-food env (the register counterpart of step_env_lds).
 template <int FMAX, int KMAX, bool FORCED, bool STD>
-__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, KMAX == 3>& ff, const MirrorLds& m, double* dist, const DevParams& P, uint64_t genv,
+__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, double* dist, const DevParams& P, uint64_t genv,
                                                 float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, int& order_cache,
                                                 const DevParams* cold SALP_STAMP_PARAM) {
   // `cold`: the device-memory copy of the launch constants (ColdBlock).  The capture bonus and the collision

@@ -102,7 +102,11 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   constexpr bool REGF = FMAX > 1 && FMAX <= 12;
   constexpr bool LDSF = FMAX > 12;
   constexpr bool MULTI = REGF || LDSF;
-  __shared__ __attribute__((aligned(16))) double2 food_lds[LDSF ? (kBlock / kWave) * FMAX * kWave : 1];
+  double2* food_lds = nullptr;
+  if constexpr (LDSF) {     // (declared only where it exists: a one-element stand-in would cost the 8-slot kernel its fourth workgroup per CU)
+    __shared__ __attribute__((aligned(16))) double2 food_lds_block[(kBlock / kWave) * FMAX * kWave];
+    food_lds = food_lds_block;
+  }
   // Per-wavefront LDS region: the observation tile (64 rows of PITCH floats) and, for the register-food kernels, the
   // fp32 mirror of the food positions behind it (8 B per slot and lane, salp_food_reg.h; lives for the whole launch).
   // 12 slots, K = 3: 6144 + 6144 B per wavefront, 49 KB per workgroup -> 3 workgroups per CU.  The tile's bytes, idle in
@@ -157,18 +161,20 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     asm volatile("" : "+v"(i));
     flush_src[j] = reinterpret_cast<const v4f*>(lds + i);
   }
-  // Event statistics (episodes, terminations, food, ...) change on rare steps only: they are
-  // accumulated with LDS integer atomics inside the rare-event branch instead of living in VGPRs.
-  __shared__ unsigned long long blk_stats[16];
-  if (tid < 16) blk_stats[tid] = 0ull;
-  __syncthreads();
+  // Event statistics (episodes, terminations, food, ...) change on rare steps only: they are accumulated with LDS integer
+  // atomics inside the rare-event branch — in 128 bytes of the wavefront's own tile, idle there — and leave with ONE
+  // global atomic instruction per wavefront and event step, into one of 64 line-sized replicas.  (Rounds 1-2 kept a
+  // 128-byte block of LDS per workgroup for the whole launch: with the mirror that was exactly what pushed the 8-slot
+  // kernel from four workgroups per CU to three.)
+  unsigned long long* const wave_stats = reinterpret_cast<unsigned long long*>(tile) + 32;   // tile bytes 256..383 (placement scratch: 0..191)
+  DevStats* const stats_replica = io.stats ? io.stats + (blockIdx.x % SALP_STATS_REPLICAS) : nullptr;
 
   using EnvT = std::conditional_t<LDSF, EnvCore, Env<FMAX>>;
   EnvT e;
   const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
   const MirrorLds mir{reinterpret_cast<float2*>(tile + TILE_FLOATS) + lane};   // REGF only
   double* const dist_col = reinterpret_cast<double*>(tile) + lane;            // REGF only: exact_order_reg's scratch
-  FoodF32<REGF ? FMAX : 1, KMAX == 3> ff;   // REGF: fp32 roundings of the food positions (salp_food_reg.h)
+  FoodF32<REGF ? FMAX : 1, food_in_registers(FMAX, KMAX)> ff;   // REGF: fp32 roundings of the food positions (salp_food_reg.h)
   FoodScan<KMAX> fq;          // MULTI: nearest-K selection of the current food set around the current pose
   int nlive = 0;              // MULTI: live foods of this env, recounted whenever the food set changes
   int order_cache = -1;       // REGF: remembered exact order of a resting swimmer's foods (step_env_reg)
@@ -299,15 +305,31 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
       const DevParams& C = cold->P;   // rare path: constants from memory, not from scalar registers
       int limit = 50;
       if (o.collected || done) order_cache = -1;      // the food set (or the episode) changes
-      if (active && io.stats) {
-        if (o.collected) atomicAdd(&blk_stats[ST_FOOD], 1ull);
-        if (o.collision) atomicAdd(&blk_stats[ST_COLL], 1ull);
-        if (done && C.autoreset) {
-          atomicAdd(&blk_stats[ST_EPISODES], 1ull);
-          atomicAdd(&blk_stats[o.terminated ? ST_TERM : ST_TRUNC], 1ull);
-          atomicAdd(&blk_stats[ST_EPLEN], (unsigned long long)e.eplen);
-          atomicAdd(&blk_stats[ST_EPRET], (unsigned long long)__double2ll_rn(e.epret * SALP_FIXED_SCALE));
+      if (io.stats) {
+        if (lane < 16) wave_stats[lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active) {
+          if (o.collected) atomicAdd(&wave_stats[ST_FOOD], 1ull);
+          if (o.collision) atomicAdd(&wave_stats[ST_COLL], 1ull);
+          if (done && C.autoreset) {
+            atomicAdd(&wave_stats[ST_EPISODES], 1ull);
+            atomicAdd(&wave_stats[o.terminated ? ST_TERM : ST_TRUNC], 1ull);
+            atomicAdd(&wave_stats[ST_EPLEN], (unsigned long long)e.eplen);
+            atomicAdd(&wave_stats[ST_EPRET], (unsigned long long)__double2ll_rn(e.epret * SALP_FIXED_SCALE));
+          }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane <= ST_EPRET) {
+          const unsigned long long v = wave_stats[lane];
+          if (v != 0) atomicAdd(&stats_replica->v[lane], v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the placement's scratch and the tile rows come next
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       SALP_STAMP(10);
 #pragma unroll 1
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        else if constexpr (REGF) place_food_coop_reg<FMAX, STD, KMAX == 3>(e, ff, mir, lane, C, genv, todo, limit, reinterpret_cast<double2*>(tile));
+        else if constexpr (REGF) place_food_coop_reg<FMAX, STD, food_in_registers(FMAX, KMAX)>(e, ff, mir, lane, C, genv, todo, limit, reinterpret_cast<double2*>(tile));
         else place_food<FMAX, STD>(e, C, genv, todo, limit);
         todo = 0;
       }
@@ -456,19 +478,13 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   }
 
   if (io.stats) {
-    // reward sum: wavefront shuffles, then one LDS atomic per wavefront; env-step count likewise.
-    // Then one 64-bit integer global atomic per block and statistic into one of 64 replicas.
+    // reward sum and env-step count: wavefront shuffles, then two 64-bit integer global atomics per wavefront
     if (!active || rows == 0) st_reward = 0.0;
     const double wr = wave_sum(st_reward);
     const int wact = wave_sum((active && rows > 0) ? 1 : 0);
-    if (lane == 0) {
-      atomicAdd(&blk_stats[ST_REWARD], (unsigned long long)__double2ll_rn(wr * SALP_FIXED_SCALE));
-      atomicAdd(&blk_stats[ST_STEPS], (unsigned long long)((long long)wact * H));
-    }
-    __syncthreads();
-    if (tid <= ST_EPRET) {
-      const unsigned long long v = blk_stats[tid];
-      if (v != 0) atomicAdd(&io.stats[blockIdx.x % SALP_STATS_REPLICAS].v[tid], v);
+    if (lane == 0 && wact > 0) {
+      atomicAdd(&stats_replica->v[ST_REWARD], (unsigned long long)__double2ll_rn(wr * SALP_FIXED_SCALE));
+      atomicAdd(&stats_replica->v[ST_STEPS], (unsigned long long)((long long)wact * H));
     }
   }
 }
