@@ -71,3 +71,32 @@ def test_ellipse_a_is_the_larger_axis_for_the_reference_radii():
             a, b = 33.0 + 6.0 * p, 33.0 + (-9.0) * p
             assert a >= b, (dur, t, a, b)
     assert 33.0 + 6.0 * 1.0 >= 33.0 + (-9.0) * 1.0 and 39.0 >= 24.0     # last exhale step, rest
+
+
+def test_fp32_food_key_error_stays_inside_the_tie_tolerance():
+    """csrc/salp_food_reg.h: the fp32 ordering pass may decide the order of two foods only when their keys are farther
+    apart than `tie_tolerance(d2) = 1.4e-7 L^2 + 8e-6 d2`; the claim behind it is that a key (fp32 squared distance from
+    fp32-rounded positions, low 4 bits replaced by the slot) is within HALF of that of the exact squared distance.
+    Emulated here with numpy float32 arithmetic for random geometry in tanks of several sizes; the GPU-side check of the
+    same property is tests/test_gpu_parity.py::test_near_tie_food_order_matches_oracle_across_scales."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for L, H in ((800, 600), (1200, 900), (500, 450), (4000, 3000)):
+        n = 400000
+        x, y = rng.uniform(0, L, n), rng.uniform(0, H, n)
+        # foods at every distance scale from 1 px to the tank's diagonal
+        r = 10.0 ** rng.uniform(0, np.log10(np.hypot(L, H)), n)
+        a = rng.uniform(0, 2 * np.pi, n)
+        fx, fy = x + r * np.cos(a), y + r * np.sin(a)
+        ok = (fx >= 0) & (fx <= L) & (fy >= 0) & (fy <= H)
+        x, y, fx, fy = x[ok], y[ok], fx[ok], fy[ok]
+        exact = (fx - x) ** 2 + (fy - y) ** 2
+        dx = (fx.astype(np.float32) - x.astype(np.float32)).astype(np.float32)
+        dy = (fy.astype(np.float32) - y.astype(np.float32)).astype(np.float32)
+        d2 = (dy.astype(np.float64) ** 2 + dx.astype(np.float64) ** 2).astype(np.float32)      # fma(dy, dy, dx dx): one rounding
+        for slot in (0, 15):
+            key = ((d2.view(np.uint32) & np.uint32(0x7FFFFFF0)) | np.uint32(slot)).view(np.float32).astype(np.float64)
+            err = np.abs(key - exact)
+            tol = 1.4e-7 * max(L, H) ** 2 + 8e-6 * exact
+            worst = float((err / tol).max())
+            assert worst <= 0.5, (L, slot, worst)
