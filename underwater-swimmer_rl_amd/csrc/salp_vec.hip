@@ -478,13 +478,23 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   }
 
   if (io.stats) {
-    // reward sum and env-step count: wavefront shuffles, then two 64-bit integer global atomics per wavefront
+    // reward sum and env-step count: wavefront shuffles, the four wavefronts' sums through 64 bytes of the (now idle)
+    // first tile, then two 64-bit integer global atomics per WORKGROUP (per wavefront they cost the H = 1 step kernel 8 %:
+    // 8192 atomics on a 14-us launch, profiles/r03/ab_notes.md session 10)
     if (!active || rows == 0) st_reward = 0.0;
     const double wr = wave_sum(st_reward);
     const int wact = wave_sum((active && rows > 0) ? 1 : 0);
-    if (lane == 0 && wact > 0) {
-      atomicAdd(&stats_replica->v[ST_REWARD], (unsigned long long)__double2ll_rn(wr * SALP_FIXED_SCALE));
-      atomicAdd(&stats_replica->v[ST_STEPS], (unsigned long long)((long long)wact * H));
+    unsigned long long* const blk = reinterpret_cast<unsigned long long*>(lds);
+    __syncthreads();                               // every wavefront is past its last tile flush
+    if (lane == 0) {
+      blk[2 * wave] = (unsigned long long)__double2ll_rn(wr * SALP_FIXED_SCALE);
+      blk[2 * wave + 1] = (unsigned long long)((long long)wact * H);
+    }
+    __syncthreads();
+    if (tid < 2) {
+      unsigned long long v = 0ull;
+      for (int w = 0; w < kBlock / kWave; ++w) v += blk[2 * w + tid];
+      if (v != 0) atomicAdd(&stats_replica->v[tid == 0 ? ST_REWARD : ST_STEPS], v);
     }
   }
 }
