@@ -330,6 +330,13 @@ def main(only=None):
         run_case(f"tie_order_f{F}", dict(preset="sac_gail", num_food_items=F, proximity_reward_weight=2.0),
                  np.zeros((220, 5, 1), np.float32), seed=40 + F, inject=tie_case(F, slots),
                  notes="equal and nearly equal food distances: stable sort on sqrt(d2), first minimum for the reward")
+    # the same with five observed foods: the build's generic instantiations (K != 3), 16 foods = positions in LDS
+    run_case("tie_order_f16_k5", dict(preset="sac_gail", num_food_items=16, max_observed_food=5, proximity_reward_weight=2.0),
+             np.zeros((220, 5, 1), np.float32), seed=61, inject=tie_case(16, (11, 3, 14, 6)),
+             notes="tie order with K = 5 of 16 foods")
+    run_case("tie_order_f9_k5", dict(preset="sac_gail", num_food_items=9, max_observed_food=5, proximity_reward_weight=2.0),
+             np.zeros((220, 5, 1), np.float32), seed=62, inject=tie_case(9, (8, 1, 5, 3)),
+             notes="tie order with K = 5 of 9 foods")
 
     # --- env_index_base: the same global envs from a shard
     run_case("shard_base_1000", dict(preset="single_food_long_horizon"), uniform_actions(128, 4, 1, 23), seed=1001,

@@ -60,13 +60,14 @@ def test_hip_matches_reference_vectors(name):
     dev.close()
 
 
-@pytest.mark.parametrize("F", [4, 12, 16])
+@pytest.mark.parametrize("F", [4, 12, 16, "16_k5", "9_k5"])
 def test_tie_order_in_whole_wavefronts_fused_rollout(F):
     """The tie-order vectors (tests/golden/gen_golden.py `tie_order_f*`: exact ties, squared distances a few ulp apart,
     a pair only fp64 can tell apart) through the UNPREDICATED fused rollout kernels: the five envs tiled 64 times into
     320 envs = five whole wavefronts, 130 steps in one launch (the swimmers rest until step ~135, so every copy sees the
     injected geometry; the copies differ from the vector only through their draw streams, which nothing uses before the
-    first thrust).  F = 4: foods in VGPRs (4 slots); 12: the sac_gail kernel; 16: foods in LDS."""
+    first thrust).  F = 4 / 12 / 16: the K = 3 register-food kernels (12: sac_gail's); 16_k5 / 9_k5: five observed foods —
+    the generic instantiations, foods in LDS (16) and in VGPRs (9)."""
     z, meta, cfg = load_fixture(f"tie_order_f{F}")
     reps, H = 64, 130
     n0 = z["actions"].shape[1]
@@ -81,7 +82,7 @@ def test_tie_order_in_whole_wavefronts_fused_rollout(F):
     dev.rollout(act, H, obs, rew, term, trunc, None, None, 0)
     ll = dev.last_launch()
     assert ll["envs_unpredicated"] == n and ll["envs_predicated"] == 0 and ll["full_signature"] == 1
-    assert ll["food_slots"] == {4: 4, 12: 12, 16: 16}[F]
+    assert (ll["food_slots"], ll["observed_capacity"]) == {4: (4, 3), 12: (12, 3), 16: (16, 3), "16_k5": (16, 8), "9_k5": (12, 8)}[F]
     want = np.tile(z["obs"][:H], (1, reps, 1))
     assert obs_diff(cfg, obs, want).max() <= 1e-5
     r = np.tile(z["reward"][:H], (1, reps))

@@ -96,8 +96,8 @@ CASES = {
     "F0_empty": dict(preset="single_food", num_food_items=0),
     "short_timeout": dict(preset="single_food", max_steps_without_food=40),
     # the unpredicated (main-launch) forms of the instantiations that only ran predicated before round 3:
-    "F16_lds_foods": dict(preset="sac_gail", num_food_items=16, max_steps_without_food=200),           # <16, 3, STD>: foods in LDS
-    "F16_lds_foods_other_tank": dict(preset="sac_gail", num_food_items=16, width=900, height=650),      # <16, 3, !STD>
+    "F16_sixteen_slots": dict(preset="sac_gail", num_food_items=16, max_steps_without_food=200),        # <16, 3, STD>
+    "F16_sixteen_slots_other_tank": dict(preset="sac_gail", num_food_items=16, width=900, height=650),  # <16, 3, !STD>
     "F14_K5_generic_lds": dict(preset="sac_gail", num_food_items=14, max_observed_food=5),              # <16, 8>: generic, foods in LDS
     "F9_K5_generic_reg": dict(preset="sac_gail", num_food_items=9, max_observed_food=5),                # <12, 8>: generic, foods in VGPRs
     "F3_other_tank": dict(preset="sac_gail", num_food_items=3, width=900, tank_margin=40.0),            # <4, 3, !STD>
@@ -106,7 +106,7 @@ CASES = {
 EXPECT_KERNEL = {
     "single_food": (1, 3, 1), "sac_gail_F12": (12, 3, 1), "class_default_F5": (8, 3, 1), "no_respawn_F3": (4, 3, 1),
     "other_tank_F1": (1, 3, 0), "other_physics_F12": (12, 3, 0), "K2_generic": (12, 8, 0),
-    "F16_lds_foods": (16, 3, 1), "F16_lds_foods_other_tank": (16, 3, 0), "F14_K5_generic_lds": (16, 8, 0),
+    "F16_sixteen_slots": (16, 3, 1), "F16_sixteen_slots_other_tank": (16, 3, 0), "F14_K5_generic_lds": (16, 8, 0),
     "F9_K5_generic_reg": (12, 8, 0), "F3_other_tank": (4, 3, 0),
 }
 
@@ -423,7 +423,7 @@ def test_near_tie_food_order_matches_oracle_across_scales(foods):
     """The order of the observed foods when two of them are ALMOST equally far — relative distance gaps from 1e-16 to
     1e-4, at distances 60..200 px — must be the reference's (stable sort on the fp64 distance,
     snake:382).  The fp32 ordering pass (csrc/salp_food_reg.h) may only decide where its error bound separates the keys
-    and must fall back to the exact order otherwise; the LDS-food path (16 foods) likewise at its 2^-44 bound.  A wrong
+    and must fall back to the exact order otherwise (4, 12 and 16 slots).  A wrong
     bound would show as two swapped food blocks (bearing columns differ by O(1)).  4096 resting swimmers (zero velocity:
     the geometry holds for the whole rollout), observe() and 20 fused steps."""
     cfg = pkg.load_env_config("sac_gail", num_food_items=foods, proximity_reward_weight=1.0)

@@ -28,7 +28,8 @@ struct FoodLds {
 
 // Result of one pass over the slots.
 //
-// Sort keys (this file: more than 12 slots; up to 12 slots: fp32 keys, salp_food_reg.h).  The K nearest are kept by a
+// Sort keys (this file: 13..16 slots with K != 3, the <16, 8> generic instantiation; everything else: fp32 keys,
+// salp_food_reg.h).  The K nearest are kept by a
 // sorted insertion on PACKED keys: the fp64 squared distance with the low 4 bits of its mantissa replaced by the slot
 // number (slots are 0..15).  All keys of an env are then distinct, so the compare-exchange of a chain stage is just
 // v_min_f64 / v_max_f64 (no index selects) and a smaller key is a nearer food.  The reference orders by sqrt(d2) with a
@@ -36,7 +37,7 @@ struct FoodLds {
 // others inside the 16 ulp of the packing stay distinct (then distance order).  The pass therefore also keeps the
 // (K + 1)-th smallest key, and when two consecutive ones of any lane are closer than 2^-44 relative the wavefront
 // runs exact_order_lds() — the reference's own key — so the order is the reference's in every case
-// (tests/golden/ref_tie_order_f16.npz).  An empty slot's key is kDeadKey | slot (finite, above any distance).
+// (tests/golden/ref_tie_order_f16_k5.npz).  An empty slot's key is kDeadKey | slot (finite, above any distance).
 // Everything that leaves the selection (offsets, distance) is recomputed from the slot's exact position.
 template <int KMAX>
 struct FoodScan {

@@ -36,11 +36,11 @@ struct MirrorLds {
   __device__ __forceinline__ void clear(int k) const { col[k * kFoodLanes] = make_float2(__builtin_nanf(""), __builtin_nanf("")); }
 };
 
-// Which instantiations keep the fp32 roundings in registers as well: the K = 3 kernels with 4 and 12 slots.  The 8-slot
-// kernel (5..8 foods) reads the mirror instead: with the copies it needs 133 VGPRs, without them 117 — under the 128 that
-// four wavefronts per SIMD allow, which its 40960 B of LDS per workgroup (exactly a quarter of the CU's) also do
-// (profiles/r03/ab_notes.md session 9); the 12-slot kernel is at three either way (49 KB) and gains 2.7 % from the copies.
-constexpr bool food_in_registers(int fmax, int kmax) { return kmax == 3 && fmax != 8; }
+// Which instantiations keep the fp32 roundings in registers as well: the K = 3 kernels with 12 and 16 slots, which LDS
+// holds at three / two wavefronts per SIMD anyway (49 / 57 KB per workgroup: room for 168 / 256 VGPRs; the 12-slot kernel
+// gains 2.7 % from the copies).  The 4- and 8-slot kernels read the mirror instead: they fit four wavefronts per SIMD by LDS
+// (32 / 40 KB), and only without the copies by registers (<= 128 VGPRs; profiles/r03/ab_notes.md sessions 9 and 12).
+constexpr bool food_in_registers(int fmax, int kmax) { return kmax == 3 && fmax >= 12; }
 
 // What the per-step pass reads (static slot index).  INREG (the K = 3 kernels): the mirror's values also in registers —
 // the pass then issues no LDS read at all (with six ds_read2st64_b64 and their waits in the pass the kernel ran 8 % slower
@@ -198,37 +198,33 @@ __device__ __forceinline__ void scan_foods_f32(const FoodF32<FMAX, food_in_regis
 // (snake:378-379), and the K nearest are K times the first minimum among the foods not yet taken — what a stable sort by
 // distance (snake:382) and the strict `<` scan of snake:350-364 produce.  Runs for the whole wavefront when some lane's
 // fp32 order is inside its error bound.
-// Careful form: the distances themselves (the device's fp64 sqrt is correctly rounded) through a [FMAX][64] block of
-// doubles private to the wavefront (`dist`: this lane's column; the kernel lends the observation tile's bytes, idle in
-// the middle of a step), rolled selection loops.  Only reached when two squared distances are within 4 ulp (see below).
+// Careful form: the distances themselves (the device's fp64 sqrt is correctly rounded), K rounds of "first minimum among
+// the foods not yet taken", each round recomputing the distances from the registers (the pose is made opaque per slot so
+// that the square roots are formed one after the other and do not stay live).  Only reached when two squared distances are within
+// 2^-44 of each other (see below): never in a benchmark run, always in tests/golden/ref_tie_order_f*.npz.
 template <int FMAX, int KMAX>
-__device__ __forceinline__ void exact_order_sqrt_reg(const Env<FMAX>& e, double* dist, int K, FoodScan<KMAX>& q) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the scratch bytes have other users (tile rows, placement)
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-  for (int k = 0; k < FMAX; ++k) {
-    const double dx = e.fx[k] - e.x, dy = e.fy[k] - e.y;
-    dist[k * kFoodLanes] = __builtin_sqrt(dx * dx + dy * dy);     // NaN for an empty slot
-  }
+__device__ __forceinline__ void exact_order_sqrt_reg(const Env<FMAX>& e, int K, FoodScan<KMAX>& q) {
   uint32_t taken = 0u;
 #pragma unroll
-  for (int s = 0; s < KMAX; ++s) {
-    int bk = -1;
-    if (s < K) {
-      double best = __builtin_inf();
+  for (int s = 0; s < KMAX; ++s) q.idx[s] = -1;
 #pragma unroll 1
-      for (int k = 0; k < FMAX; ++k) {
-        const double d = dist[k * kFoodLanes];
-        const bool take = !((taken >> k) & 1u) && (d < best);      // NaN never; ties keep the lower slot
-        best = take ? d : best;
-        bk = take ? k : bk;
-      }
-      taken |= (bk >= 0) ? (1u << bk) : 0u;
+  for (int s = 0; s < K; ++s) {
+    int bk = -1;
+    double best = __builtin_inf();
+#pragma unroll
+    for (int k = 0; k < FMAX; ++k) {
+      double ex = e.x, ey = e.y;
+      asm volatile("" : "+v"(ex), "+v"(ey));      // one slot after the other, every round anew: short live ranges
+      const double dx = e.fx[k] - ex, dy = e.fy[k] - ey;
+      const double d = __builtin_sqrt(dx * dx + dy * dy);           // NaN for an empty slot
+      const bool take = !((taken >> k) & 1u) && (d < best);         // NaN never; ties keep the lower slot
+      best = take ? d : best;
+      bk = take ? k : bk;
     }
-    q.idx[s] = bk;
+    taken |= (bk >= 0) ? (1u << bk) : 0u;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) q.idx[j] = (j == s) ? bk : q.idx[j];
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // Usual form: ONE pass of packed fp64 keys — the reference's squared distance dx^2 + dy^2 with the slot number in its low
 // 4 mantissa bits, sorted insertion on v_min_f64 / v_max_f64 (round 2's per-step pass, ~13 instructions per slot).  sqrt
@@ -239,7 +235,7 @@ __device__ __forceinline__ void exact_order_sqrt_reg(const Env<FMAX>& e, double*
 // a swimmer rests for the first ~135 steps of an episode, so a near tie at reset recurs on every one of them, and the
 // launch ends with its slowest wavefront (with three 36-slot rounds here the 12-food kernel lost 12 %, ab_notes.md).
 template <int FMAX, int KMAX>
-__device__ __forceinline__ void exact_order_reg(const Env<FMAX>& e, double* dist, int K, FoodScan<KMAX>& q) {
+__device__ __forceinline__ void exact_order_reg(const Env<FMAX>& e, int K, FoodScan<KMAX>& q) {
   const double dead = dead_key();
   double key[KMAX + 1];
 #pragma unroll
@@ -266,7 +262,7 @@ __device__ __forceinline__ void exact_order_reg(const Env<FMAX>& e, double* dist
     close = close || (s < K && key_found(key[s + 1]) && (key[s + 1] - key[s] < key[s + 1] * 5.6843418860808015e-14));   // 2^-44
     q.idx[s] = (s < K && key_found(key[s])) ? key_slot(key[s]) : -1;
   }
-  if (__any(close)) exact_order_sqrt_reg<FMAX, KMAX>(e, dist, K, q);
+  if (__any(close)) exact_order_sqrt_reg<FMAX, KMAX>(e, K, q);
 }
 
 // fp32 geometry of the K selected foods from their mirror positions (the same differences the pass formed).
@@ -288,13 +284,12 @@ __device__ __forceinline__ void resolve_f32(const MirrorLds& m, int K, float xf,
 }
 
 // Selection of the current food set around the current pose: pass, exact order where needed, geometry.
-// `dist`: see exact_order_reg.
 template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT>
-__device__ __forceinline__ void select_foods_reg(const Env<FMAX>& e, const FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, double* dist, int K,
+__device__ __forceinline__ void select_foods_reg(const Env<FMAX>& e, const FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, int K,
                                                  float tol_c0, FoodScan<KMAX>& q, int& cnt) {
   const float xf = (float)e.x, yf = (float)e.y;
   scan_foods_f32<FMAX, KMAX, ALLLIVE, COUNT>(ff, m, K, xf, yf, tol_c0, q, cnt);
-  if (__any(q.tie)) exact_order_reg<FMAX, KMAX>(e, dist, K, q);
+  if (__any(q.tie)) exact_order_reg<FMAX, KMAX>(e, K, q);
   resolve_f32<KMAX, ALLLIVE>(m, K, xf, yf, q);
 }
 
@@ -332,7 +327,7 @@ __device__ __forceinline__ void clear_slot(Env<FMAX>& e, FoodF32<FMAX, INREG>& f
 
 // One reference step of a multi-food env (the register counterpart of step_env_lds).
 template <int FMAX, int KMAX, bool FORCED, bool STD>
-__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, double* dist, const DevParams& P, uint64_t genv,
+__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, const DevParams& P, uint64_t genv,
                                                 float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, int& order_cache,
                                                 const DevParams* cold SALP_STAMP_PARAM) {
   // `cold`: the device-memory copy of the launch constants (ColdBlock).  The capture bonus and the collision
@@ -387,20 +382,25 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, food
     // order is computed once per episode and remembered (`order_cache`: K slot numbers, 4 bits each; < 0: none; the
     // kernel drops it whenever the env's food set changes or it is reset).  Without this a wavefront with one such lane
     // runs the exact pass on 135 of its steps, and a launch ends with its slowest wavefront.
+    constexpr bool kOrderCache = 5 * KMAX <= 30;            // K = 3: 15 bits of one register (the generic K <= 8 recomputes)
     const bool resting = (e.vx == 0.0) && (e.vy == 0.0);
-    const bool cached = q.tie && resting && (order_cache >= 0);
+    const bool cached = kOrderCache && q.tie && resting && (order_cache >= 0);
     SALP_COUNT(0, __any(q.tie && !cached));
     if (__any(q.tie && !cached)) {
-      exact_order_reg<FMAX, KMAX>(e, dist, Ksel, q);        // every lane: the exact order is the order
-      int pack = 0;
+      exact_order_reg<FMAX, KMAX>(e, Ksel, q);        // every lane: the exact order is the order
+      if (kOrderCache) {
+        int pack = 0;
 #pragma unroll
-      for (int s = 0; s < KMAX; ++s) pack |= (q.idx[s] & 15) << (4 * s);
-      order_cache = resting ? pack : order_cache;
+        for (int s = 0; s < KMAX; ++s) pack |= ((q.idx[s] + 1) & 31) << (5 * s);      // 5 bits per entry: slot + 1, 0 = none
+        order_cache = resting ? pack : order_cache;
+      }
     }
+    if (kOrderCache) {
 #pragma unroll
-    for (int s = 0; s < KMAX; ++s) {
-      const int k = (order_cache >> (4 * s)) & 15;
-      q.idx[s] = cached ? (k == 15 ? -1 : k) : q.idx[s];
+      for (int s = 0; s < KMAX; ++s) {
+        const int k = ((order_cache >> (5 * s)) & 31) - 1;
+        q.idx[s] = cached ? k : q.idx[s];
+      }
     }
   }
   if (all_live) resolve_f32<KMAX, true>(m, Ksel, xf, yf, q);

@@ -87,7 +87,7 @@ struct ColdBlock {
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
 template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ? SALP_MULTI_WAVES : 2) : 1))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ? SALP_MULTI_WAVES : 2) : (KMAX == 3 ? 2 : 1)))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
   // LDS tile of the wavefront's 64 observation rows.  Banking (MI355X_MICROARCH.md §LDS): ds_write_b128 goes
   // in 8 groups of 8 lanes over banks (a/4) mod 32, ds_read_b128 in 4 groups of 16 lanes ({0-3,12-15,20-27},
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   constexpr int PITCH = SWZ ? 4 * QMAX : 4 * QMAX + 4;     // LDS row pitch in floats
   // Where the food positions of a multi-food env live: up to 12 slots in VGPRs with an fp32 mirror in LDS
   // (salp_food_reg.h), above that in LDS (salp_food_lds.h); one food is plain registers.
-  constexpr bool REGF = FMAX > 1 && FMAX <= 12;
-  constexpr bool LDSF = FMAX > 12;
+  constexpr bool REGF = FMAX > 1 && (FMAX <= 12 || KMAX == 3);   // K = 3: every slot count; generic K: up to 12 slots
+  constexpr bool LDSF = FMAX > 1 && !REGF;                         // generic K with 13..16 slots
   constexpr bool MULTI = REGF || LDSF;
   double2* food_lds = nullptr;
   if constexpr (LDSF) {     // (declared only where it exists: a one-element stand-in would cost the 8-slot kernel its fourth workgroup per CU)
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   // <= the tile for every instantiation) and the placement's accepted points.
   constexpr int TILE_FLOATS = kWave * PITCH;
   constexpr int WAVE_FLOATS = TILE_FLOATS + (REGF ? kWave * 2 * FMAX : 0);
-  static_assert(!REGF || 2 * FMAX <= PITCH, "the exact order's [FMAX][64] doubles must fit in the tile");
+  static_assert(!REGF || 4 * FMAX <= kWave * PITCH, "the placement's FMAX accepted points (16 B each) must fit in the tile");
   __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * WAVE_FLOATS];
 
   const int tid = threadIdx.x;
@@ -173,7 +173,6 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
   EnvT e;
   const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
   const MirrorLds mir{reinterpret_cast<float2*>(tile + TILE_FLOATS) + lane};   // REGF only
-  double* const dist_col = reinterpret_cast<double*>(tile) + lane;            // REGF only: exact_order_reg's scratch
   FoodF32<REGF ? FMAX : 1, food_in_registers(FMAX, KMAX)> ff;   // REGF: fp32 roundings of the food positions (salp_food_reg.h)
   FoodScan<KMAX> fq;          // MULTI: nearest-K selection of the current food set around the current pose
   int nlive = 0;              // MULTI: live foods of this env, recounted whenever the food set changes
@@ -258,9 +257,9 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
     else if constexpr (REGF) {
 #ifdef SALP_EXP_STAMPS
       { StampAcc* stamps_ = &stamps; SALP_STAMP(0); }
-      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, ff, mir, dist_col, P, genv, c0, c1, K, fq, nlive, order_cache, &cold->P, &stamps);
+      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, ff, mir, P, genv, c0, c1, K, fq, nlive, order_cache, &cold->P, &stamps);
 #else
-      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, ff, mir, dist_col, P, genv, c0, c1, K, fq, nlive, order_cache, &cold->P);
+      o = step_env_reg<FMAX, KMAX, FORCED, STD>(e, ff, mir, P, genv, c0, c1, K, fq, nlive, order_cache, &cold->P);
 #endif
     }
     else {
@@ -344,7 +343,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
               resolve<KMAX>(food, K, e.x, e.y, fq);
               observe_lds<KMAX, STD>(e, C, rmax, K, fq, nlive, false, 0.f, fo);
             } else if constexpr (REGF) {
-              select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, dist_col, K, CV(tie_c0), fq, nlive);
+              select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, K, CV(tie_c0), fq, nlive);
               observe_lds<KMAX, STD>(e, C, rmax, K, fq, nlive, false, 0.f, fo);
             } else {
               observe<FMAX, KMAX, STD>(e, C, rmax, have_rel, o.rel, fo);
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 12 ? (KMAX == 3 ?
         have_rel = false;
       }
       if constexpr (REGF) {   // likewise (the exact order's scratch and the placement's are the same idle tile bytes, used in turn)
-        select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, dist_col, K, CV(tie_c0), fq, nlive);
+        select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, K, CV(tie_c0), fq, nlive);
         have_rel = false;
       }
     }
