@@ -12,6 +12,7 @@ from underwater_swimmer_rl_amd import _capi
 
 def main():
     variants, rounds, launches, n, H, preset = [], 6, 5, 262144, 250, "single_food_long_horizon"
+    want_fin = False
     it = iter(sys.argv[1:])
     for a in it:
         if a == "--rounds": rounds = int(next(it))
@@ -19,6 +20,7 @@ def main():
         elif a == "--envs": n = int(next(it))
         elif a == "--chunk": H = int(next(it))
         elif a == "--preset": preset = next(it)
+        elif a == "--final-obs": want_fin = True      # the non-FULL output signature (terminal observations written)
         else:
             k, v = a.split("=", 1); variants.append((k, os.path.abspath(v)))
     # a variant name ending in "+gen" runs the device-generated-action mode (act = NULL, actions
@@ -30,6 +32,7 @@ def main():
     rew = torch.empty((H, n), device=dev)
     term = torch.empty((H, n), dtype=torch.uint8, device=dev)
     trunc = torch.empty((H, n), dtype=torch.uint8, device=dev)
+    fin = torch.empty((H, n, cfg.obs_dim), device=dev) if want_fin else None
     handles = {}
     for name, path in variants:
         lib = _capi.load_library(path)
@@ -42,7 +45,7 @@ def main():
         a_in = None if "+gen" in name else vp(act.data_ptr())
         a_out = vp(act.data_ptr()) if name.endswith("+gen") else None
         _capi.check(lib, lib.salp_vec_rollout(h, a_in, H, vp(obs.data_ptr()), vp(rew.data_ptr()),
-                    vp(term.data_ptr()), vp(trunc.data_ptr()), None, a_out, 1, vp(torch.cuda.current_stream().cuda_stream)), "rollout")
+                    vp(term.data_ptr()), vp(trunc.data_ptr()), vp(fin.data_ptr()) if fin is not None else None, a_out, 1, vp(torch.cuda.current_stream().cuda_stream)), "rollout")
     times = {name: [] for name, _ in variants}
     warm = int(os.environ.get("AB_WARM", "8"))   # advance every variant to the same (desynchronised) phase mix
     for name, _ in variants:
