@@ -223,8 +223,9 @@ int64_t salp_vec_global_step(const salp_vec_t* h);
 
 /* Which kernel instantiation the handle's most recent step / rollout call ran (introspection for tests and profiles; no
  * reference counterpart): info[0] food slots of the kernel (1, 4, 8, 12, 16), [1] observed-food capacity (3, or 8 = the
- * generic instantiation), [2] 1 = the reference's constants compiled in as literals, [3] forced breathing, [4] 1 = the
- * common output signature (obs, reward, terminated, truncated; no final_obs / info), [5] 1 = actions drawn in the kernel,
+ * generic instantiation), [2] 1 = the reference's constants compiled in as literals, [3] forced breathing, [4] the
+ * output signature the kernel was compiled for: 1 = obs, reward, terminated, truncated and nothing else, 2 = those four plus
+ * final_obs and / or info, 0 = some of the four is NULL (every store tested; always 0 for the generic instantiation), [5] 1 = actions drawn in the kernel,
  * [6] envs served by the unpredicated launch (whole wavefronts), [7] envs served by the predicated launch. */
 int salp_vec_last_launch(const salp_vec_t* h, int64_t info[8]);
 

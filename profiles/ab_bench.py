@@ -13,6 +13,7 @@ from underwater_swimmer_rl_amd import _capi
 def main():
     variants, rounds, launches, n, H, preset = [], 6, 5, 262144, 250, "single_food_long_horizon"
     want_fin = False
+    overrides = {}
     it = iter(sys.argv[1:])
     for a in it:
         if a == "--rounds": rounds = int(next(it))
@@ -20,12 +21,14 @@ def main():
         elif a == "--envs": n = int(next(it))
         elif a == "--chunk": H = int(next(it))
         elif a == "--preset": preset = next(it)
+        elif a == "--set":                           # --set width=801 (a SalpSnakeEnv keyword on top of the preset)
+            k, v = next(it).split("=", 1); overrides[k] = (int(v) if v.lstrip("-").isdigit() else (v == "true") if v in ("true", "false") else float(v))
         elif a == "--final-obs": want_fin = True      # the non-FULL output signature (terminal observations written)
         else:
             k, v = a.split("=", 1); variants.append((k, os.path.abspath(v)))
     # a variant name ending in "+gen" runs the device-generated-action mode (act = NULL, actions
     # written to act_out); "+gennoout" the same without act_out
-    cfg = pkg.load_env_config(preset)
+    cfg = pkg.load_env_config(preset, **overrides)
     dev = torch.device("cuda", 0)
     act = torch.rand((H, n, cfg.act_dim), device=dev) * 2 - 1
     obs = torch.empty((H, n, cfg.obs_dim), device=dev)

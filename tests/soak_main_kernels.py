@@ -1,5 +1,5 @@
 """Soak run (not collected by pytest) of the UNPREDICATED main-launch kernels — the register-food (2..12 slots),
-16-slot (13..16 foods) and one-food STD instantiations, FULL and non-FULL output signatures — against the oracle, at batch
+16-slot (13..16 foods) and one-food STD instantiations, all three output signatures — against the oracle, at batch
 sizes above the small-batch threshold (n x H > 2^22, so the range splits into the main launch over whole wavefronts and
 the ragged tail).  Random reference-constant configurations: every flag, reward and time-out setting of
 test_gpu_parity._random_cfg with K = 3.   python3 tests/soak_main_kernels.py [cases]   (last run: 0 failures)"""

@@ -81,7 +81,8 @@ def test_tie_order_in_whole_wavefronts_fused_rollout(F):
     trunc = np.empty((H, n), np.uint8)
     dev.rollout(act, H, obs, rew, term, trunc, None, None, 0)
     ll = dev.last_launch()
-    assert ll["envs_unpredicated"] == n and ll["envs_predicated"] == 0 and ll["full_signature"] == 1
+    assert ll["envs_unpredicated"] == n and ll["envs_predicated"] == 0
+    assert ll["full_signature"] == (1 if isinstance(F, int) else 0)      # the generic (K != 3) instantiation tests every store
     assert (ll["food_slots"], ll["observed_capacity"]) == {4: (4, 3), 12: (12, 3), 16: (16, 3), "16_k5": (16, 8), "9_k5": (12, 8)}[F]
     want = np.tile(z["obs"][:H], (1, reps, 1))
     assert obs_diff(cfg, obs, want).max() <= 1e-5

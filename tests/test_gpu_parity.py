@@ -145,7 +145,8 @@ def test_rollout_parity(name):
     assert st["episodes"] == int(done.sum())
     assert st["terminated"] == int(ref["terminated"].sum()) and st["truncated"] == int(ref["truncated"].sum())
     ll = dev.last_launch()      # 2048 envs = 32 whole wavefronts: the unpredicated kernel, non-FULL signature (final_obs)
-    assert ll["envs_unpredicated"] == n and ll["envs_predicated"] == 0 and ll["full_signature"] == 0
+    assert ll["envs_unpredicated"] == n and ll["envs_predicated"] == 0
+    assert ll["full_signature"] == (2 if ll["observed_capacity"] == 3 else 0)    # main outputs + final_obs + info
     if name in EXPECT_KERNEL:
         assert (ll["food_slots"], ll["observed_capacity"], ll["literal_constants"]) == EXPECT_KERNEL[name], ll
     print(f"{name}: max obs diff {dmax:.3g}, max rel reward diff {rmax:.3g}, episodes {st['episodes']}, kernel {ll}")
@@ -320,6 +321,41 @@ def test_sharding_is_trajectory_invariant():
         assert np.array_equal(full[k][:, : n // 2], lo[k]) and np.array_equal(full[k][:, n // 2:], hi[k]), k
     for d in (d0, d1, d2):
         d.close()
+
+
+@pytest.mark.parametrize("foods", [1, 5, 12, 16])
+def test_partial_output_signatures_match_oracle(foods):
+    """Callers may leave any output NULL (include/salp_vec.h): the kernels compiled for that case test every store.  Two
+    such signatures per slot count in the unpredicated launch (2048 envs) — no reward / truncated, and reward + flags
+    without observations (with terminal observations) — against the oracle, and the state after both."""
+    cfg = make_cfg(dict(preset="sac_gail", num_food_items=foods, max_steps_without_food=60))
+    n, H, seed = 2048, 200, 5
+    act = make_actions(cfg, 2 * H, n, seed=9)
+    dev = SalpLib(cfg, n, device_id=0, seed=seed)
+    orc = ol.OracleVec(cfg, n, seed=seed)
+    ref1 = orc.rollout(act[:H], want_final=True)
+    ref2 = orc.rollout(act[H:], want_final=True)
+    obs = np.empty((H, n, cfg.obs_dim), np.float32)
+    term = np.empty((H, n), np.uint8)
+    dev.rollout(np.ascontiguousarray(act[:H]), H, obs, None, term, None, None, None, 0)
+    ll = dev.last_launch()
+    assert ll["full_signature"] == 0 and ll["envs_unpredicated"] == n and ll["food_slots"] >= foods
+    assert np.array_equal(term, ref1["terminated"])
+    assert obs_diff(cfg, obs, ref1["obs"]).max() <= OBS_TOL
+    rew = np.empty((H, n), np.float32)
+    trunc = np.empty((H, n), np.uint8)
+    fin = np.full((H, n, cfg.obs_dim), np.nan, np.float32)
+    dev.rollout(np.ascontiguousarray(act[H:]), H, None, rew, term, trunc, fin, None, 0)
+    assert dev.last_launch()["full_signature"] == 0
+    assert np.array_equal(term, ref2["terminated"]) and np.array_equal(trunc, ref2["truncated"])
+    r = ref2["reward"]
+    assert (np.abs(rew - r) / np.maximum(1.0, np.abs(r))).max() <= REW_TOL
+    done = (ref2["terminated"] | ref2["truncated"]).astype(bool)
+    assert done.any() and np.array_equal(np.isnan(fin[..., 0]), ~done)
+    assert obs_diff(cfg, fin[done], ref2["final_obs"][done]).max() <= OBS_TOL
+    assert_state_parity(cfg, dev, orc, f"partial_F{foods}")
+    dev.close()
+    orc.close()
 
 
 def test_properties_full_size_262144():

@@ -187,7 +187,8 @@ class SalpLib:
         return {k: getattr(s, k) for k, _ in CStats._fields_}
 
     def last_launch(self) -> dict:
-        """The kernel instantiation of the most recent step / rollout call (salp_vec_last_launch)."""
+        """The kernel instantiation of the most recent step / rollout call (salp_vec_last_launch).  `full_signature`: 1 = the four
+        main outputs only, 2 = the four plus final_obs / info, 0 = some main output absent."""
         a = (ctypes.c_int64 * 8)()
         check(self.lib, self.lib.salp_vec_last_launch(self._h, a), "salp_vec_last_launch")
         keys = ("food_slots", "observed_capacity", "literal_constants", "forced", "full_signature", "actions_in_kernel",

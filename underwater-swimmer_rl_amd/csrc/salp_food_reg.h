@@ -40,7 +40,12 @@ struct MirrorLds {
 // holds at three / two wavefronts per SIMD anyway (49 / 57 KB per workgroup: room for 168 / 256 VGPRs; the 12-slot kernel
 // gains 2.7 % from the copies).  The 4- and 8-slot kernels read the mirror instead: they fit four wavefronts per SIMD by LDS
 // (32 / 40 KB), and only without the copies by registers (<= 128 VGPRs; profiles/r03/ab_notes.md sessions 9 and 12).
-constexpr bool food_in_registers(int fmax, int kmax) { return kmax == 3 && fmax >= 12; }
+#ifndef SALP_INREG_ALWAYS
+#define SALP_INREG_ALWAYS 0
+#endif
+constexpr bool food_in_registers(int fmax, int kmax, bool std_consts, bool full) {
+  return kmax == 3 && (fmax > 12 || (fmax == 12 && (SALP_INREG_ALWAYS || (std_consts && full))));
+}
 
 // What the per-step pass reads (static slot index).  INREG (the K = 3 kernels): the mirror's values also in registers —
 // the pass then issues no LDS read at all (with six ds_read2st64_b64 and their waits in the pass the kernel ran 8 % slower
@@ -157,8 +162,8 @@ __device__ __forceinline__ void select_keys(const uint32_t (&key)[FMAX], uint32_
 // q.idx (-1: none) and whether the fp32 order of this lane is inside its error bound (q.tie: then exact_order_reg decides).
 // ALLLIVE: every slot of every lane holds a food (the steady state with respawn): no NaN can occur, the NaN guard of
 // the distance sum and the found tests are dropped.
-template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT>
-__device__ __forceinline__ void scan_foods_f32(const FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, int K, float xf, float yf, float tol_c0,
+template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT, bool INREG>
+__device__ __forceinline__ void scan_foods_f32(const FoodF32<FMAX, INREG>& ff, const MirrorLds& m, int K, float xf, float yf, float tol_c0,
                                                FoodScan<KMAX>& q, int& cnt) {
   uint32_t key[FMAX];
   float dsum = 0.f;
@@ -284,8 +289,8 @@ __device__ __forceinline__ void resolve_f32(const MirrorLds& m, int K, float xf,
 }
 
 // Selection of the current food set around the current pose: pass, exact order where needed, geometry.
-template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT>
-__device__ __forceinline__ void select_foods_reg(const Env<FMAX>& e, const FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, int K,
+template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT, bool INREG>
+__device__ __forceinline__ void select_foods_reg(const Env<FMAX>& e, const FoodF32<FMAX, INREG>& ff, const MirrorLds& m, int K,
                                                  float tol_c0, FoodScan<KMAX>& q, int& cnt) {
   const float xf = (float)e.x, yf = (float)e.y;
   scan_foods_f32<FMAX, KMAX, ALLLIVE, COUNT>(ff, m, K, xf, yf, tol_c0, q, cnt);
@@ -326,8 +331,8 @@ __device__ __forceinline__ void clear_slot(Env<FMAX>& e, FoodF32<FMAX, INREG>& f
 }
 
 // One reference step of a multi-food env (the register counterpart of step_env_lds).
-template <int FMAX, int KMAX, bool FORCED, bool STD>
-__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, food_in_registers(FMAX, KMAX)>& ff, const MirrorLds& m, const DevParams& P, uint64_t genv,
+template <int FMAX, int KMAX, bool FORCED, bool STD, bool INREG>
+__device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, INREG>& ff, const MirrorLds& m, const DevParams& P, uint64_t genv,
                                                 float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, int& order_cache,
                                                 const DevParams* cold SALP_STAMP_PARAM) {
   // `cold`: the device-memory copy of the launch constants (ColdBlock).  The capture bonus and the collision

@@ -34,6 +34,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 #define SALP_MULTI_WAVES 3     // multi-food kernels (<= 12 slots): <= 168 VGPRs, 3 wavefronts per SIMD (a fourth: +0.7 %, r02 session 10)
+#ifndef SALP_MULTI_WAVES_OTHER
+#define SALP_MULTI_WAVES_OTHER 3
+#endif
 #ifndef SALP_SMALL_WAVES
 #define SALP_SMALL_WAVES 4     // 4- and 8-slot kernels with the literal constants: 128 VGPRs (their LDS allows four workgroups per CU); without the
 #endif                         // bound the non-FULL signatures landed on 129 = three per SIMD, 22 % slower (ab_notes.md session 14); STD = false: 3
@@ -89,8 +92,10 @@ struct ColdBlock {
 // GEN = actions are generated in the kernel (salp_vec_rollout with act == NULL): no read stream at
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
-template <int FMAX, int KMAX, bool FORCED, bool STD, bool FULL, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 && STD ? SALP_SMALL_WAVES : (FMAX <= 12 ? (KMAX == 3 ? SALP_MULTI_WAVES : 2) : (KMAX == 3 ? 2 : 1))))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+template <int FMAX, int KMAX, bool FORCED, bool STD, int SIG, bool RAGGED, bool GEN>
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 && STD ? SALP_SMALL_WAVES : (FMAX <= 12 ? (KMAX == 3 ? (STD ? SALP_MULTI_WAVES : SALP_MULTI_WAVES_OTHER) : 2) : (KMAX == 3 ? 2 : 1))))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+  constexpr bool FULL = SIG != 0;         // obs, reward, terminated, truncated all present: their stores are unconditional
+  constexpr bool EXTRAS = SIG != 1;       // final_obs / info may be present (tested per use; SIG 0: every output is tested)
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
   // LDS tile of the wavefront's 64 observation rows.  Banking (MI355X_MICROARCH.md §LDS): ds_write_b128 goes
   // in 8 groups of 8 lanes over banks (a/4) mod 32, ds_read_b128 in 4 groups of 16 lanes ({0-3,12-15,20-27},
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
   EnvT e;
   const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
   const MirrorLds mir{reinterpret_cast<float2*>(tile + TILE_FLOATS) + lane};   // REGF only
-  FoodF32<REGF ? FMAX : 1, food_in_registers(FMAX, KMAX)> ff;   // REGF: fp32 roundings of the food positions (salp_food_reg.h)
+  FoodF32<REGF ? FMAX : 1, food_in_registers(FMAX, KMAX, STD, SIG == 1)> ff;   // REGF: fp32 roundings of the food positions (salp_food_reg.h)
   FoodScan<KMAX> fq;          // MULTI: nearest-K selection of the current food set around the current pose
   int nlive = 0;              // MULTI: live foods of this env, recounted whenever the food set changes
   int order_cache = -1;       // REGF: remembered exact order of a resting swimmer's foods (step_env_reg)
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
       if (FULL || io.reward) io.reward[rowbase + env] = o.reward;
       if (FULL || io.terminated) io.terminated[rowbase + env] = o.terminated ? 1 : 0;
       if (FULL || io.truncated) io.truncated[rowbase + env] = o.truncated ? 1 : 0;
-      if (!FULL && io.info) {
+      if (EXTRAS && io.info) {
         int32_t* ip = io.info + (rowbase + env) * SALP_INFO_COLS;
         ip[SALP_INFO_FOOD_COLLECTED] = e.fc;
         ip[SALP_INFO_STEPS_SINCE_FOOD] = e.ssf;
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
 #pragma unroll 1
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1 && done && C.autoreset) {
-          if (!FULL && io.final_obs && active) {
+          if (EXTRAS && io.final_obs && active) {
             float fo[12 + 4 * KMAX];
             if constexpr (LDSF) {   // the terminal observation sees the respawned food (pass 0)
               bool c_; int h_;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        else if constexpr (REGF) place_food_coop_reg<FMAX, STD, food_in_registers(FMAX, KMAX)>(e, ff, mir, lane, C, genv, todo, limit, reinterpret_cast<double2*>(tile));
+        else if constexpr (REGF) place_food_coop_reg<FMAX, STD, food_in_registers(FMAX, KMAX, STD, SIG == 1)>(e, ff, mir, lane, C, genv, todo, limit, reinterpret_cast<double2*>(tile));
         else place_food<FMAX, STD>(e, C, genv, todo, limit);
         todo = 0;
       }
@@ -742,15 +747,29 @@ int validate(const salp_config_t* c) {
 typedef void (*rollout_fn)(DevParams, DevState, IOPtrs, int, int64_t, int64_t, const ColdBlock*);
 typedef void (*reset_fn)(DevParams, DevState, const uint8_t*, float*, int);
 
+// Output signatures (template parameter SIG): kSigMain = obs, reward, terminated, truncated and nothing else — every
+// store of the step loop is unconditional, so the compiler can count the stores issued after the action prefetch and wait
+// for the prefetch alone; kSigExtras = the same four plus final_obs and / or info (salp_vec_step, rollouts that keep the
+// terminal observations): the four main streams stay unconditional, only the extras are tested (the terminal rows are
+// written in the rare-event region, the three info words per step); kSigPartial = some main output is NULL: every
+// store is tested, the step ends in a full drain (a 12-food rollout with final_obs ran 22 % slower in that form,
+// profiles/r03/ab_notes.md session 15).  The one-wavefront predicated launches exist as kSigMain and kSigPartial only.
+enum { kSigPartial = 0, kSigMain = 1, kSigExtras = 2 };
+template <int FMAX, int KMAX, bool FORCED, bool STD, bool RAGGED, bool GEN>
+rollout_fn pick_sig(int sig) {
+  if constexpr (GEN) return (rollout_fn)salp_rollout_kernel<FMAX, KMAX, FORCED, STD, kSigMain, RAGGED, true>;
+  else {
+    if (sig == kSigMain) return (rollout_fn)salp_rollout_kernel<FMAX, KMAX, FORCED, STD, kSigMain, RAGGED, false>;
+    if constexpr (!RAGGED)
+      if (sig == kSigExtras) return (rollout_fn)salp_rollout_kernel<FMAX, KMAX, FORCED, STD, kSigExtras, false, false>;
+    return (rollout_fn)salp_rollout_kernel<FMAX, KMAX, FORCED, STD, kSigPartial, RAGGED, false>;
+  }
+}
 template <int FMAX, int KMAX, bool STD, bool RAGGED>
-rollout_fn pick_rollout(bool forced, bool full, bool gen) {
-  if (full && gen)   // in-kernel action generation exists for the FULL output signature
-    return forced ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, true, RAGGED, true>
-                  : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, true, RAGGED, true>;
-  if (forced) return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, true, RAGGED, false>
-                          : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, true, STD, false, RAGGED, false>;
-  return full ? (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, true, RAGGED, false>
-              : (rollout_fn)salp_rollout_kernel<FMAX, KMAX, false, STD, false, RAGGED, false>;
+rollout_fn pick_rollout(bool forced, int sig, bool gen) {
+  if (sig == kSigMain && gen)   // in-kernel action generation exists for the main-only output signature
+    return forced ? pick_sig<FMAX, KMAX, true, STD, RAGGED, true>(sig) : pick_sig<FMAX, KMAX, false, STD, RAGGED, true>(sig);
+  return forced ? pick_sig<FMAX, KMAX, true, STD, RAGGED, false>(sig) : pick_sig<FMAX, KMAX, false, STD, RAGGED, false>(sig);
 }
 
 // K = 3 (every preset): kernels by food-slot count, with the reference's constants as literals (STD) or — any other
@@ -760,23 +779,23 @@ rollout_fn pick_rollout(bool forced, bool full, bool gen) {
 bool can_generate_in_kernel(const salp_vec* h, bool full) { return full && h->kmax == 3; }
 
 template <bool STD, bool RAGGED>
-rollout_fn rollout_kernel_k3(const salp_vec* h, bool forced, bool full, bool gen) {
-  if (h->fmax == 1) return pick_rollout<1, 3, STD, RAGGED>(forced, full, gen);
-  if (h->fmax == 4) return pick_rollout<4, 3, STD, RAGGED>(forced, full, gen);
-  if (h->fmax == 8) return pick_rollout<8, 3, STD, RAGGED>(forced, full, gen);
-  if (h->fmax == 12) return pick_rollout<12, 3, STD, RAGGED>(forced, full, gen);
-  return pick_rollout<16, 3, STD, RAGGED>(forced, full, gen);
+rollout_fn rollout_kernel_k3(const salp_vec* h, bool forced, int sig, bool gen) {
+  if (h->fmax == 1) return pick_rollout<1, 3, STD, RAGGED>(forced, sig, gen);
+  if (h->fmax == 4) return pick_rollout<4, 3, STD, RAGGED>(forced, sig, gen);
+  if (h->fmax == 8) return pick_rollout<8, 3, STD, RAGGED>(forced, sig, gen);
+  if (h->fmax == 12) return pick_rollout<12, 3, STD, RAGGED>(forced, sig, gen);
+  return pick_rollout<16, 3, STD, RAGGED>(forced, sig, gen);
 }
 template <bool RAGGED>
-rollout_fn rollout_kernel_for(const salp_vec* h, bool full, bool gen) {
+rollout_fn rollout_kernel_for(const salp_vec* h, int sig, bool gen) {
   const bool forced = h->P.forced != 0;
   if (h->kmax == 3)
-    return h->std_consts ? rollout_kernel_k3<true, RAGGED>(h, forced, full, gen) : rollout_kernel_k3<false, RAGGED>(h, forced, full, gen);
+    return h->std_consts ? rollout_kernel_k3<true, RAGGED>(h, forced, sig, gen) : rollout_kernel_k3<false, RAGGED>(h, forced, sig, gen);
   if (h->fmax <= 12)   // K != 3 with up to 12 foods: the register-food form of the generic instantiation (2 wavefronts per SIMD, not 1)
-    return forced ? (rollout_fn)salp_rollout_kernel<12, 8, true, false, false, RAGGED, false>
-                  : (rollout_fn)salp_rollout_kernel<12, 8, false, false, false, RAGGED, false>;
-  return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, false, RAGGED, false>
-                : (rollout_fn)salp_rollout_kernel<16, 8, false, false, false, RAGGED, false>;
+    return forced ? (rollout_fn)salp_rollout_kernel<12, 8, true, false, kSigPartial, RAGGED, false>
+                  : (rollout_fn)salp_rollout_kernel<12, 8, false, false, kSigPartial, RAGGED, false>;
+  return forced ? (rollout_fn)salp_rollout_kernel<16, 8, true, false, kSigPartial, RAGGED, false>
+                : (rollout_fn)salp_rollout_kernel<16, 8, false, false, kSigPartial, RAGGED, false>;
 }
 template <bool STD>
 reset_fn reset_kernel_k3(const salp_vec* h) {
@@ -828,7 +847,8 @@ struct Bump {  // carve sub-buffers out of the staging allocation
 };
 
 int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
-  const bool full = io.obs && io.reward && io.terminated && io.truncated && !io.final_obs && !io.info;
+  const bool main_outputs = io.obs && io.reward && io.terminated && io.truncated;
+  const int sig = !main_outputs ? kSigPartial : ((io.final_obs || io.info) ? kSigExtras : kSigMain);
   const bool gen = io.act == nullptr;               // only reached when can_generate_in_kernel()
   // envs in full wavefronts: unpredicated kernel
   int64_t n_full = h->n / kWave * kWave;
@@ -836,17 +856,17 @@ int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
   // range instead of two; the predicates only cost when the write stream is the bound.
   if (n_full < h->n && h->n * (int64_t)H <= (int64_t)1 << 22) n_full = 0;
   h->last_launch[0] = h->fmax; h->last_launch[1] = h->kmax; h->last_launch[2] = (h->kmax == 3) ? h->std_consts : 0;
-  h->last_launch[3] = h->P.forced; h->last_launch[4] = full; h->last_launch[5] = gen;
+  h->last_launch[3] = h->P.forced; h->last_launch[4] = (h->kmax == 3) ? sig : kSigPartial; h->last_launch[5] = gen;
   h->last_launch[6] = n_full; h->last_launch[7] = h->n - n_full;
   if (n_full > 0) {
     const unsigned grid = (unsigned)((n_full + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(rollout_kernel_for<false>(h, full, gen), dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
+    hipLaunchKernelGGL(rollout_kernel_for<false>(h, sig, gen), dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
                        (int64_t)0, n_full, (const ColdBlock*)h->cold);
     HIP_TRY(hipGetLastError());
   }
   if (n_full < h->n) {                              // the last n % 64 envs (or the whole small batch): predicated stores
     const unsigned rgrid = (unsigned)((h->n - n_full + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(rollout_kernel_for<true>(h, full, gen), dim3(rgrid), dim3(kBlock), 0, st, h->P, h->S, io, H,
+    hipLaunchKernelGGL(rollout_kernel_for<true>(h, sig, gen), dim3(rgrid), dim3(kBlock), 0, st, h->P, h->S, io, H,
                        n_full, h->n, (const ColdBlock*)h->cold);
     HIP_TRY(hipGetLastError());
   }
