@@ -57,6 +57,8 @@ __host__ __device__ inline int bw_hold(uint32_t w) { return (int)((w >> 18) & 7u
 typedef const uint32_t __attribute__((address_space(4))) seed_word_t;
 
 // Constants derived on the host in fp64 exactly as the reference derives them.
+struct DevParams;
+typedef const DevParams __attribute__((address_space(4))) dev_params_c;   // the handle's copy in device memory, read with scalar loads
 struct DevParams {
   // geometry / legacy constants
   double W, H, half_W, half_H;
@@ -84,6 +86,8 @@ struct DevParams {
   seed_word_t* seed;        // the two key words of the draw streams, in DEVICE memory (the handle's ColdBlock): a kernel
                             // reads them where it draws, so salp_vec_reseed() changes them without changing any launch
                             // parameter — a hipGraph captured before a reseed replays with the new key
+  dev_params_c* self;       // this block in DEVICE memory (the handle's ColdBlock): where the STD = false kernels read their
+                            // constants, function by function (open_consts below)
   uint64_t env_base;        // global index of local env 0
   int64_t n;                // envs in this handle
   int64_t pitch;            // row pitch (elements) of the SoA state blocks
@@ -107,8 +111,32 @@ struct StdConsts {
   static constexpr float tie_c0 = 0.0896f;
   static constexpr int inhale_dur = 120, exhale_dur = 150, cycle_len = 330;
 };
-// CV(name): the constant `name` for this instantiation
-#define CV(name) (STD ? StdConsts::name : P.name)
+// CV(name): the constant `name` for this instantiation.  STD = false: ~50 doubles that differ from the literals.  Taken from
+// the by-value launch parameter they are all loop-invariant scalars: the compiler loads them once, needs ~100 SGPRs for
+// them and spills ~90-115 of those to VGPR lanes, so that nearly every use in the step loop costs a v_readlane (the 8- and
+// 12-slot kernels ran 17-25 % behind their literal-constant forms, profiles/r03/ab_notes.md session 15).  Instead every
+// function that uses constants opens the handle's device copy through a pointer made opaque there (SALP_CONSTS): the scalar
+// loads (s_load_dwordx2..x16, scalar cache) stay in that function, and the registers are free again after it.
+// Measured (ab_pc_f*.json): 4- and 8-slot kernels -5 ... -15 % (125 VGPRs, four wavefronts per SIMD again); one-food +1.4 %,
+// 12- and 16-slot kernels +13 % (two / three wavefronts per SIMD do not hide the scalar-load waits) — so a kernel chooses:
+// it hands its functions a parameter block whose `self` is a compile-time NULL to keep the by-value constants.
+template <bool STD>
+__device__ __forceinline__ dev_params_c* open_consts(const DevParams& P) {
+  if constexpr (STD) return nullptr;
+  else {
+    if (__builtin_constant_p(P.self == nullptr) && P.self == nullptr) return nullptr;   // resolved after inlining
+    // (the rare paths hand in the memory copy itself: its `self` word may arrive through a vector load)
+    const uint64_t a = (uint64_t)(uintptr_t)P.self;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    dev_params_c* p = (dev_params_c*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    asm volatile("" : "+s"(p));
+    __builtin_assume(p != nullptr);      // CV() then drops its by-value alternative
+    return p;
+  }
+}
+#define SALP_CONSTS [[maybe_unused]] dev_params_c* const PC_ = open_consts<STD>(P)
+#define CV(name) (STD ? StdConsts::name : (PC_ ? PC_->name : P.name))
 
 // SoA state rows (device layout; distinct from the public snapshot layout)
 enum { SF_X = 0, SF_Y, SF_VX, SF_VY, SF_TH, SF_OM, SF_NOZ, SF_WATER, SF_EPRET, SF_FOOD0 };
@@ -234,6 +262,7 @@ __device__ __forceinline__ U4 next_block(EnvCore& e, const DevParams& P, uint64_
 
 template <int FMAX, bool STD>
 __device__ __forceinline__ void draw_xy(EnvCore& e, const DevParams& P, uint64_t genv, double& x, double& y) {
+  SALP_CONSTS;
   const U4 w = next_block(e, P, genv);
   x = CV(food_xlo) + CV(food_xspan) * u53(w.x, w.y);
   y = CV(food_ylo) + CV(food_yspan) * u53(w.z, w.w);
@@ -379,6 +408,7 @@ __device__ __forceinline__ double sin_nozzle_t(tbl_double* T, double x) {
 // Ellipse semi-axes implied by the post-step state (see SALP_I_SHAPE_HOLD in salp_vec.h).
 template <bool STD>
 __device__ __forceinline__ void shape_of(const DevParams& P, uint32_t packed, double water, double& a, double& b) {
+  SALP_CONSTS;
   const int phase = bw_phase(packed), timer = bw_timer(packed), dur = bw_dur(packed), hold = bw_hold(packed);
   if (hold == 7) { a = CV(R); b = CV(R); return; }
   if (hold != 0) {
@@ -401,6 +431,7 @@ __device__ __forceinline__ void shape_of(const DevParams& P, uint32_t packed, do
 // (at reset slots fill in order, snake:120; at respawn snake:261-264).  `todo` = foods still to place.
 template <int FMAX, bool STD>
 __device__ __forceinline__ void place_food(Env<FMAX>& e, const DevParams& P, uint64_t genv, int todo, int limit) {
+  SALP_CONSTS;
   int attempts = 0;
 #pragma unroll 1
   while (__any(todo > 0)) {
@@ -437,6 +468,7 @@ __device__ __forceinline__ void place_food(Env<FMAX>& e, const DevParams& P, uin
 // F_base: base_num_food_items of this launch (the one constant a caller may change between launches).
 template <bool STD>
 __device__ __forceinline__ int reset_core(EnvCore& e, const DevParams& P, uint64_t genv, int F_base) {
+  SALP_CONSTS;
   e.x = CV(half_W); e.y = CV(half_H); e.vx = 0.0; e.vy = 0.0; e.th = 0.0; e.om = 0.0;
   e.noz = 0.0; e.water = 0.0; e.epret = 0.0;
   e.packed = pack_breath(0, 0, bw_dur(e.packed), 7);
@@ -470,6 +502,7 @@ struct ThrustTerms { double ax, ay, bx, by, cx, cy, om; };
 template <bool STD>
 __device__ __forceinline__ ThrustTerms jet_thrust_terms(double th, double noz, double water, double r, uint32_t rng,
                                                         uint64_t genv, const DevParams& P) {
+  SALP_CONSTS;
   ThrustTerms t;
   tbl_double* TT = thrust_table();
   const double T = mul_s(CV(thrust_force) * water, TT[TT_K04]);
@@ -629,6 +662,7 @@ struct StepOut {
 // legacy:119-156 up to and including the wall bounce; returns r = max(ellipse_a, ellipse_b) of this step.
 template <bool FORCED, bool STD>
 __device__ __forceinline__ double step_head(EnvCore& e, const DevParams& P, uint64_t genv, float a0, float a1 SALP_STAMP_PARAM) {
+  SALP_CONSTS;
   int phase = bw_phase(e.packed), timer = bw_timer(e.packed), dur = bw_dur(e.packed);
   // legacy:121-135
   double nd;
@@ -770,6 +804,7 @@ __device__ __forceinline__ void step_tail(EnvCore& e, const DevParams& P, StepOu
 
 template <int FMAX, bool FORCED, bool STD>
 __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, uint64_t genv, float a0, float a1 SALP_STAMP_PARAM) {
+  SALP_CONSTS;
   const double r = step_head<FORCED, STD>(e, P, genv, a0, a1 SALP_STAMP_PASS);
   StepOut o;
   o.rmax = r;
@@ -830,6 +865,7 @@ __device__ __forceinline__ StepOut step_env(Env<FMAX>& e, const DevParams& P, ui
 template <int FMAX, int KMAX, bool STD>
 __device__ __forceinline__ void observe(const Env<FMAX>& e, const DevParams& P, double rmax, bool have_rel, float rel0,
                                         float (&o)[12 + 4 * KMAX]) {
+  SALP_CONSTS;
   const int K = (KMAX == 3) ? 3 : P.K;
   // normalisations in fp32 on the rounded fp64 state (<= 1.5 ulp of the reference's f32 value)
   o[0] = (float)e.x * (float)CV(inv_W);

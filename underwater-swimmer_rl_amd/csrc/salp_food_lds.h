@@ -192,6 +192,7 @@ __device__ __forceinline__ void resolve(const FoodLds& f, int K, double x, doubl
 template <int KMAX, bool FORCED, bool STD>
 __device__ __forceinline__ StepOut step_env_lds(EnvCore& e, const FoodLds& f, const DevParams& P, uint64_t genv, float a0, float a1,
                                                 int K, FoodScan<KMAX>& q, int& nlive) {
+  SALP_CONSTS;
   const double r = step_head<FORCED, STD>(e, P, genv, a0, a1);
   StepOut o;
   o.rmax = r;
@@ -230,6 +231,7 @@ __device__ __forceinline__ StepOut step_env_lds(EnvCore& e, const FoodLds& f, co
 template <int KMAX, bool STD, bool ALLFOUND = false>
 __device__ __forceinline__ void observe_lds(const EnvCore& e, const DevParams& P, double rmax, int K, const FoodScan<KMAX>& q,
                                             int nlive, bool have_rel, float rel0, float (&o)[12 + 4 * KMAX]) {
+  SALP_CONSTS;
   o[0] = (float)e.x * (float)CV(inv_W);
   o[1] = (float)e.y * (float)CV(inv_H);
   o[2] = (float)e.vx * 0.2f;
@@ -292,6 +294,7 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
 template <int FMAX, bool STD>
 __device__ __forceinline__ void place_food_coop(EnvCore& e, double2* wave_block, int lane, const DevParams& P, uint64_t genv,
                                                 int todo, int limit) {
+  SALP_CONSTS;
   unsigned long long need = __ballot(todo > 0);
   const double min2 = CV(min_food_dist2);
   while (need) {                                   // wave-uniform: one env at a time

@@ -335,6 +335,7 @@ template <int FMAX, int KMAX, bool FORCED, bool STD, bool INREG>
 __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, INREG>& ff, const MirrorLds& m, const DevParams& P, uint64_t genv,
                                                 float a0, float a1, int K, FoodScan<KMAX>& q, int& nlive, int& order_cache,
                                                 const DevParams* cold SALP_STAMP_PARAM) {
+  SALP_CONSTS;
   // `cold`: the device-memory copy of the launch constants (ColdBlock).  The capture bonus and the collision
   // penalty are read from it inside the wave-uniform branches that need them (a few percent of the steps), so
   // their four fp64 constants and two predicate masks do not sit in — and get spilled from — scalar registers.
@@ -442,6 +443,7 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, INRE
 template <int FMAX, bool STD, bool INREG>
 __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, FoodF32<FMAX, INREG>& ff, const MirrorLds& m, int lane, const DevParams& P, uint64_t genv,
                                                     int todo, int limit, double2* scratch) {
+  SALP_CONSTS;
   unsigned long long need = __ballot(todo > 0);
   const double min2 = CV(min_food_dist2);
   // empty slots of the own env as a bit mask (bit k: slot k < F is empty)

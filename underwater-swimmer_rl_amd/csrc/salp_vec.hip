@@ -93,7 +93,13 @@ struct ColdBlock {
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
 template <int FMAX, int KMAX, bool FORCED, bool STD, int SIG, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 && STD ? SALP_SMALL_WAVES : (FMAX <= 12 ? (KMAX == 3 ? (STD ? SALP_MULTI_WAVES : SALP_MULTI_WAVES_OTHER) : 2) : (KMAX == 3 ? 2 : 1))))) void salp_rollout_kernel(DevParams P, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 && STD ? SALP_SMALL_WAVES : (FMAX <= 12 ? (KMAX == 3 ? (STD ? SALP_MULTI_WAVES : SALP_MULTI_WAVES_OTHER) : 2) : (KMAX == 3 ? 2 : 1))))) void salp_rollout_kernel(DevParams P_arg, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+  // STD = false: where the hot path's constants come from (open_consts, salp_device.h) — the device copy, function by
+  // function, for the 4- and 8-slot kernels; the by-value launch parameters for the others
+  constexpr bool MEMC = !STD && KMAX == 3 && (FMAX == 4 || FMAX == 8);
+  DevParams P_byval = P_arg;
+  P_byval.self = nullptr;
+  const DevParams& P = (STD || MEMC) ? P_arg : P_byval;
   constexpr bool FULL = SIG != 0;         // obs, reward, terminated, truncated all present: their stores are unconditional
   constexpr bool EXTRAS = SIG != 1;       // final_obs / info may be present (tested per use; SIG 0: every output is tested)
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
@@ -351,7 +357,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
               resolve<KMAX>(food, K, e.x, e.y, fq);
               observe_lds<KMAX, STD>(e, C, rmax, K, fq, nlive, false, 0.f, fo);
             } else if constexpr (REGF) {
-              select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, K, CV(tie_c0), fq, nlive);
+              select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, K, (STD ? StdConsts::tie_c0 : C.tie_c0), fq, nlive);
               observe_lds<KMAX, STD>(e, C, rmax, K, fq, nlive, false, 0.f, fo);
             } else {
               observe<FMAX, KMAX, STD>(e, C, rmax, have_rel, o.rel, fo);
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
             }
           }
           limit = 100;
-          rmax = CV(R);
+          rmax = STD ? StdConsts::R : C.R;
           have_rel = false;
         }
         if constexpr (LDSF) {
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
         have_rel = false;
       }
       if constexpr (REGF) {   // likewise (the exact order's scratch and the placement's are the same idle tile bytes, used in turn)
-        select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, K, CV(tie_c0), fq, nlive);
+        select_foods_reg<FMAX, KMAX, false, true>(e, ff, mir, K, (STD ? StdConsts::tie_c0 : C.tie_c0), fq, nlive);
         have_rel = false;
       }
     }
@@ -942,6 +948,7 @@ int salp_vec_create(const salp_config_t* cfg, int64_t n_envs, int device_id, uin
   hipError_t e4 = hipMalloc((void**)&h->cold, sizeof(ColdBlock));
   if (e4 == hipSuccess) {
     h->P.seed = (seed_word_t*)(uintptr_t)h->cold->seed;   // device address; the kernels read the key words through it
+    h->P.self = (dev_params_c*)(uintptr_t)&h->cold->P;    // likewise the constants of the STD = false kernels
     ColdBlock cb;
     cb.P = h->P; cb.S = h->S;
     cb.seed[0] = (uint32_t)seed; cb.seed[1] = (uint32_t)(seed >> 32);
