@@ -132,15 +132,16 @@ def sac_first_capture(device, world: int, rank: int, envs: int = 4096, max_steps
 def secondary_kernels(device, envs: int, chunk: int, launches: int = 10, warmup: int = 3):
     """The rollout kernels the headline does not run, timed the same way (HIP events on the launch stream around each
     launch, inputs resident in HBM), AFTER the headline and outside its timed region: the 12-food kernel of the preset
-    BASELINE configs[4] names (configs/sac_gail.yaml:9 — the kernel furthest below its roofline).  At most
+    BASELINE configs[4] names (configs/sac_gail.yaml:9), the same parameters with 16 foods (the 16-slot kernel: the K = 3
+    kernel furthest below its roofline) and with 5 (the reference class's default count: the 8-slot kernel).  At most
     `warmup + launches` <= 15 launches per entry."""
     import torch
     import underwater_swimmer_rl_amd as pkg
     from underwater_swimmer_rl_amd.vector_env import SalpVectorEnv
     out = []
-    for preset in ("sac_gail",):
+    for preset, over in (("sac_gail", {}), ("sac_gail", {"num_food_items": 16}), ("sac_gail", {"num_food_items": 5})):
         try:
-            cfg = pkg.load_env_config(preset)
+            cfg = pkg.load_env_config(preset, **over)
             env = SalpVectorEnv(cfg, envs, device=str(device), seed=0, env_index_base=0)
             gen = torch.Generator(device=device)
             gen.manual_seed(4321)
@@ -155,7 +156,8 @@ def secondary_kernels(device, envs: int, chunk: int, launches: int = 10, warmup:
             bpe = algorithmic_bytes_per_env_step(cfg, chunk)
             avg = sum(ms) / len(ms)
             ach = bpe * envs * chunk / (avg * 1e-3) / 1e9
-            out.append({"preset": preset, "kernel": f"salp_rollout_kernel<{12 if cfg.num_food_items > 8 else cfg.num_food_items},3> "
+            slots = env._lib.last_launch()["food_slots"]
+            out.append({"preset": preset, "overrides": over, "kernel": f"salp_rollout_kernel<{slots},3> "
                         f"({cfg.num_food_items} foods in VGPRs + fp32 mirror in LDS)", "envs": envs, "chunk": chunk,
                         "launches": launches, "warmup": warmup, "avg_kernel_ms": avg, "min_kernel_ms": min(ms), "max_kernel_ms": max(ms),
                         "achieved": ach, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS, "bound": "hbm (priced); VALU-issue (actual)",
@@ -165,8 +167,36 @@ def secondary_kernels(device, envs: int, chunk: int, launches: int = 10, warmup:
             del act
             torch.cuda.empty_cache()
         except Exception as e:   # noqa: BLE001 — an extra, never the headline
-            out.append({"preset": preset, "error": f"{type(e).__name__}: {e}"})
+            out.append({"preset": preset, "overrides": over, "error": f"{type(e).__name__}: {e}"})
     return out
+
+
+def step_mode(device, envs: int, preset: str, iters: int = 200, warmup: int = 20):
+    """`salp_vec_step` (one launch per env step, the reference's own call shape) on device tensors, back to back on one
+    stream: device time per step by HIP events over `iters` calls.  Accounting: state both ways
+    (48 + 8 F bytes each) + action + observation + reward + two flags per env-step."""
+    import torch
+    from underwater_swimmer_rl_amd.vector_env import SalpVectorEnv
+    try:
+        env = SalpVectorEnv(preset, num_envs=envs, device=str(device), seed=0)
+        act = torch.rand((envs, env.act_dim), device=device) * 2 - 1
+        for _ in range(warmup):
+            env.step(act, want_final_observation=False)
+        torch.cuda.synchronize(device)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            env.step(act, want_final_observation=False)
+        e.record(); e.synchronize()
+        us = s.elapsed_time(e) / iters * 1e3
+        cfg = env.cfg
+        bpe = 2 * (48 + 8 * cfg.num_food_items) + 4 * cfg.act_dim + 4 * cfg.obs_dim + 4 + 2
+        env.close()
+        return {"preset": preset, "envs": envs, "calls": iters, "us_per_step": us, "env_steps_per_s": envs / (us * 1e-6),
+                "algorithmic_bytes_per_env_step": bpe, "achieved": bpe * envs / (us * 1e-6) / 1e9, "unit": "GB/s",
+                "frac": bpe * envs / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    except Exception as e:   # noqa: BLE001 — an extra, never the headline
+        return {"preset": preset, "envs": envs, "error": f"{type(e).__name__}: {e}"}
 
 
 CONFIG2_ENVS = 262144        # BASELINE configs[2]: one GPU
@@ -493,6 +523,7 @@ def main():
             env = None
             torch.cuda.empty_cache()
         line["secondary_kernels"] = secondary_kernels(device, n, H)
+        line["step_per_launch"] = [step_mode(device, n, args.preset), step_mode(device, n, "sac_gail"), step_mode(device, 4096, "sac_gail")]
     if not args.no_sac_probe and not rehearsal and not force_sharded and (world == 1 or args.sac_probe):
         probe = sac_first_capture(device, world if senv is not None else 1, rank)   # every rank takes part (collectives)
         line["sac_first_capture"] = probe
