@@ -2,7 +2,8 @@
 16-slot (13..16 foods) and one-food STD instantiations, all three output signatures — against the oracle, at batch
 sizes above the small-batch threshold (n x H > 2^22, so the range splits into the main launch over whole wavefronts and
 the ragged tail).  Random reference-constant configurations: every flag, reward and time-out setting of
-test_gpu_parity._random_cfg with K = 3.   python3 tests/soak_main_kernels.py [cases]   (last run: 0 failures)"""
+test_gpu_parity._random_cfg with K = 3; from case 30 on also other tanks / physics
+(the STD = false kernels).   python3 tests/soak_main_kernels.py [cases]   (last run: 0 failures)"""
 import os
 import sys
 
@@ -14,7 +15,7 @@ import test_gpu_parity as T   # noqa: E402
 import oracle_lib as ol       # noqa: E402
 import underwater_swimmer_rl_amd as pkg   # noqa: E402
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0
 for case in range(cases):
     rng = np.random.default_rng(9000 + case)
@@ -24,6 +25,16 @@ for case in range(cases):
               efficiency_bonus=float(rng.choice([0.0, 1.0])), max_steps_without_food=int(rng.integers(30, 500)),
               food_reward=float(rng.uniform(1, 20)), collision_penalty=float(-rng.uniform(1, 60)),
               time_penalty=float(-rng.uniform(0, 0.5)))
+    other = case >= 30 and bool(rng.random() < 0.6)    # cases 30+: also the STD = false kernels (K = 3, another tank / physics)
+    if other:
+        kw.update(width=int(rng.integers(500, 1200)), height=int(rng.integers(450, 900)), tank_margin=float(rng.uniform(20, 60)),
+                  base_radius=float(rng.uniform(18, 34)), max_thrust_force=float(rng.uniform(60, 160)),
+                  drag_coefficient=float(rng.uniform(0.95, 0.995)), angular_drag=float(rng.uniform(0.9, 0.99)),
+                  max_nozzle_angle=float(rng.uniform(0.6, 1.3)), nozzle_response_rate=float(rng.uniform(0.02, 0.2)),
+                  food_radius=float(rng.uniform(8, 25)), min_food_distance=float(rng.uniform(40, 110)))
+        if rng.random() < 0.5:
+            kw.update(inhale_duration=int(rng.integers(10, 200)), exhale_duration=int(rng.integers(20, 250)),
+                      rest_duration=int(rng.integers(0, 120)))
     cfg = pkg.load_env_config("single_food", **kw)
     n = 4096 + int(rng.integers(0, 200))
     H = 1100
@@ -37,7 +48,8 @@ for case in range(cases):
         d = T.assert_parity(cfg, got, ref, f"case {case}")
         T.assert_state_parity(cfg, dev, orc, f"case {case}")
         st = dev.stats()
-        print(f"case {case}: F={F} n={n} final={want_final} forced={kw['forced_breathing']} respawn={kw['respawn_food']} "
+        ll = dev.last_launch()
+        print(f"case {case}: F={F} literal={ll['literal_constants']} sig={ll['full_signature']} n={n} final={want_final} forced={kw['forced_breathing']} respawn={kw['respawn_food']} "
               f"max obs diff {d[0]:.2e} episodes {st['episodes']} food {st['food_collected']}", flush=True)
         dev.close(); orc.close()
     except AssertionError as e:
