@@ -33,7 +33,9 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
+#ifndef SALP_MULTI_WAVES
 #define SALP_MULTI_WAVES 3     // multi-food kernels (<= 12 slots): <= 168 VGPRs, 3 wavefronts per SIMD (a fourth: +0.7 %, r02 session 10)
+#endif
 #ifndef SALP_MULTI_WAVES_OTHER
 #define SALP_MULTI_WAVES_OTHER 3
 #endif
