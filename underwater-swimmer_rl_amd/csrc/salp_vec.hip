@@ -34,7 +34,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
 #ifndef SALP_MULTI_WAVES
-#define SALP_MULTI_WAVES 3     // multi-food kernels (<= 12 slots): <= 168 VGPRs, 3 wavefronts per SIMD (a fourth: +0.7 %, r02 session 10)
+#define SALP_MULTI_WAVES 3     // 12-slot kernels: <= 168 VGPRs, 3 wavefronts per SIMD (four: 49 KB of LDS forbid it, and a timing build at 128 VGPRs / 36 KB was 13 % slower, r03 session 17)
 #endif
 #ifndef SALP_MULTI_WAVES_OTHER
 #define SALP_MULTI_WAVES_OTHER 3
