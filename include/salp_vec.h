@@ -228,6 +228,11 @@ int64_t salp_vec_global_step(const salp_vec_t* h);
  * final_obs and / or info, 0 = some of the four is NULL (every store tested; always 0 for the generic instantiation), [5] 1 = actions drawn in the kernel,
  * [6] envs served by the unpredicated launch (whole wavefronts), [7] envs served by the predicated launch. */
 int salp_vec_last_launch(const salp_vec_t* h, int64_t info[8]);
+/* What that kernel (the unpredicated one when both were launched) holds per workgroup of 256 threads, from the runtime
+ * (hipFuncGetAttributes, hipOccupancyMaxActiveBlocksPerMultiprocessor): info[0] registers per thread (VGPRs), [1] static LDS
+ * bytes, [2] scratch (spill) bytes per thread, [3] workgroups resident per CU = wavefronts per SIMD.  The design's occupancy
+ * claims (one food >= 4, 4 / 8 slots 4, 12 slots 3, 16 slots 2) are tested against it; no reference counterpart. */
+int salp_vec_last_kernel_resources(const salp_vec_t* h, int32_t info[4]);
 
 /* The curriculum's attribute poke `env.base_num_food_items = k` (src/salp/training/continuous_trainer.py:409-411;
  * src/salp/environments/salp_snake_env.py:36): the number of foods placed at every LATER reset of an env

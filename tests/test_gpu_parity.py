@@ -358,6 +358,27 @@ def test_partial_output_signatures_match_oracle(foods):
     orc.close()
 
 
+@pytest.mark.parametrize("foods,tank,min_wg,max_vgprs", [
+    (1, False, 4, 128), (3, False, 4, 128), (5, False, 4, 128), (8, False, 4, 128), (12, False, 3, 168), (16, False, 2, 256),
+    (5, True, 4, 128), (8, True, 4, 128), (1, True, 4, 128), (12, True, 3, 168), (16, True, 2, 256)])
+def test_kernel_occupancy_matches_the_design(foods, tank, min_wg, max_vgprs):
+    """DESIGN.md section 3.1's occupancy table as the runtime reports it for the kernels actually launched (no timing):
+    workgroups of 256 threads resident per CU (= wavefronts per SIMD), VGPRs, no scratch — for the main-only signature and
+    for the one with terminal observations, literal constants and an 801-wide tank.  (Two signatures of the 4- / 8-slot kernels
+    once sat at 129 VGPRs — three per SIMD, 22 % slower — without any test noticing.)"""
+    cfg = make_cfg(dict(preset="sac_gail", num_food_items=foods, **(dict(width=801) if tank else {})))
+    n, H = 2048, 4
+    act = make_actions(cfg, H, n, seed=1)
+    dev = SalpLib(cfg, n, device_id=0, seed=3)
+    for want_final in (False, True):
+        run_device(cfg, n, act, dev=dev, want_final=want_final)
+        ll, res = dev.last_launch(), dev.last_kernel_resources()
+        assert ll["literal_constants"] == (0 if tank else 1) and ll["full_signature"] == (2 if want_final else 1)
+        assert res["workgroups_per_cu"] >= min_wg, (ll, res)
+        assert res["vgprs"] <= max_vgprs and res["scratch_bytes"] == 0, (ll, res)
+    dev.close()
+
+
 def test_properties_full_size_262144():
     """BASELINE.json configs[2] size, checked through size-independent properties: bounded
     observations, breathing period 273 in forced mode, |nozzle| <= 1, positions inside the tank,

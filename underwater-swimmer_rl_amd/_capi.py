@@ -28,7 +28,7 @@ EXPORTS = (
     "salp_vec_num_food", "salp_vec_device", "salp_vec_reset", "salp_vec_step", "salp_vec_rollout",
     "salp_vec_observe", "salp_vec_get_state", "salp_vec_set_state", "salp_vec_get_stats",
     "salp_vec_clear_stats", "salp_vec_global_step", "salp_vec_set_base_num_food", "salp_vec_base_num_food",
-    "salp_vec_reseed", "salp_vec_last_launch",
+    "salp_vec_reseed", "salp_vec_last_launch", "salp_vec_last_kernel_resources",
 )
 
 
@@ -90,6 +90,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     L.salp_vec_clear_stats.argtypes = [vp]
     if path is None or hasattr(L, "salp_vec_last_launch"):
         L.salp_vec_last_launch.argtypes = [vp, ctypes.POINTER(ctypes.c_int64)]
+    if path is None or hasattr(L, "salp_vec_last_kernel_resources"):
+        L.salp_vec_last_kernel_resources.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     if path is None or hasattr(L, "salp_vec_reseed"):   # (an explicit path may be an older A/B variant, profiles/ab_bench.py)
         L.salp_vec_reseed.argtypes = [vp, u64, vp, u32, vp]
     L.salp_vec_global_step.argtypes = [vp]
@@ -194,6 +196,12 @@ class SalpLib:
         keys = ("food_slots", "observed_capacity", "literal_constants", "forced", "full_signature", "actions_in_kernel",
                 "envs_unpredicated", "envs_predicated")
         return dict(zip(keys, (int(v) for v in a)))
+
+    def last_kernel_resources(self) -> dict:
+        """Registers, LDS, scratch and resident workgroups per CU of the most recent call's kernel (salp_vec_last_kernel_resources)."""
+        a = (ctypes.c_int32 * 4)()
+        check(self.lib, self.lib.salp_vec_last_kernel_resources(self._h, a), "salp_vec_last_kernel_resources")
+        return dict(zip(("vgprs", "lds_bytes", "scratch_bytes", "workgroups_per_cu"), (int(v) for v in a)))
 
     def clear_stats(self):
         check(self.lib, self.lib.salp_vec_clear_stats(self._h), "salp_vec_clear_stats")

@@ -692,6 +692,7 @@ struct salp_vec {
   size_t nf_rows;
   hipStream_t last_stream;   // the stream of the handle's most recent launch: what get_stats / destroy wait for
   int64_t last_launch[8];    // salp_vec_last_launch
+  const void* last_kernel;   // the main (else the predicated) kernel of the most recent launch: salp_vec_last_kernel_resources
 };
 
 namespace {
@@ -868,13 +869,17 @@ int launch_rollout(salp_vec* h, const IOPtrs& io, int H, hipStream_t st) {
   h->last_launch[6] = n_full; h->last_launch[7] = h->n - n_full;
   if (n_full > 0) {
     const unsigned grid = (unsigned)((n_full + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(rollout_kernel_for<false>(h, sig, gen), dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
+    const rollout_fn fn = rollout_kernel_for<false>(h, sig, gen);
+    h->last_kernel = (const void*)fn;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, st, h->P, h->S, io, H,
                        (int64_t)0, n_full, (const ColdBlock*)h->cold);
     HIP_TRY(hipGetLastError());
   }
   if (n_full < h->n) {                              // the last n % 64 envs (or the whole small batch): predicated stores
     const unsigned rgrid = (unsigned)((h->n - n_full + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(rollout_kernel_for<true>(h, sig, gen), dim3(rgrid), dim3(kBlock), 0, st, h->P, h->S, io, H,
+    const rollout_fn fn = rollout_kernel_for<true>(h, sig, gen);
+    if (n_full == 0) h->last_kernel = (const void*)fn;
+    hipLaunchKernelGGL(fn, dim3(rgrid), dim3(kBlock), 0, st, h->P, h->S, io, H,
                        n_full, h->n, (const ColdBlock*)h->cold);
     HIP_TRY(hipGetLastError());
   }
@@ -1015,6 +1020,19 @@ int64_t salp_vec_global_step(const salp_vec_t* h) { return h ? h->global_step : 
 int salp_vec_last_launch(const salp_vec_t* h, int64_t info[8]) {
   if (!h || !info) return fail(SALP_ERR_INVALID, "handle/info is NULL");
   memcpy(info, h->last_launch, sizeof(h->last_launch));
+  return SALP_OK;
+}
+
+int salp_vec_last_kernel_resources(const salp_vec_t* h, int32_t info[4]) {
+  if (!h || !info) return fail(SALP_ERR_INVALID, "handle/info is NULL");
+  if (!h->last_kernel) return fail(SALP_ERR_INVALID, "no step / rollout call has been issued on this handle");
+  DeviceScope dev_scope;
+  HIP_TRY(dev_scope.enter(h->device));
+  hipFuncAttributes attr;
+  HIP_TRY(hipFuncGetAttributes(&attr, h->last_kernel));
+  int blocks = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, h->last_kernel, kBlock, 0));
+  info[0] = attr.numRegs; info[1] = (int32_t)attr.sharedSizeBytes; info[2] = (int32_t)attr.localSizeBytes; info[3] = blocks;
   return SALP_OK;
 }
 
