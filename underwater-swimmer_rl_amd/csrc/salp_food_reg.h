@@ -483,6 +483,38 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, FoodF32<FMAX, 
       }
       int j = 0;                                   // first candidate of this batch not yet judged
       uint32_t filled = 0u;                        // slots of env L that received a point in this batch
+#ifndef SALP_EXP_NO_FAST_RESET
+      // First batch of an autoreset (no food yet, the empty slots are 0 .. nE-1): the same sequential rule on bit masks.  A
+      // candidate's standing is `blocked` — the union of the accepted candidates' conflict rows (one ballot each) — instead of
+      // a per-lane flag re-tested every round, and the accepted points are handed over together: the k-th accepted lane
+      // writes slot k.  ~25 instead of ~52 instructions per accepted food (12 foods per reset, 5 % of the wavefront-steps).
+      const int nE = __builtin_popcount(empty);
+      if (present == 0u && todo_l > 1 && empty == ((nE >= 32) ? ~0u : ((1u << nE) - 1u))) {
+        const unsigned long long okm0 = __ballot(ok);
+        unsigned long long blocked = 0ull, acc = 0ull;
+        while (todo_l > 0 && j < kFoodLanes) {
+          const unsigned long long okm = okm0 & ~blocked & (~0ull << j);
+          const int first_ok = okm ? (__ffsll((long long)okm) - 1) : kFoodLanes;
+          const int forced = j + (limit_l - attempts);          // accepted whatever it is
+          const int a = __builtin_amdgcn_readfirstlane(first_ok < forced ? first_ok : forced);
+          if (a >= kFoodLanes) { attempts += kFoodLanes - j; j = kFoodLanes; break; }
+          const double ax = bcast_lane(x, a), ay = bcast_lane(y, a);
+          const double dx = x - ax, dy = y - ay;
+          blocked |= __ballot(dx * dx + dy * dy < min2);
+          acc |= 1ull << a;
+          todo_l -= 1;
+          attempts = 0;
+          j = a + 1;
+        }
+        const int nacc = __builtin_popcountll(acc);
+        const int nput = nacc < nE ? nacc : nE;
+        const int rank = __builtin_popcountll(acc & ((1ull << lane) - 1ull));
+        if (((acc >> lane) & 1ull) && rank < nput) scratch[rank] = make_double2(x, y);
+        filled = (nput >= 32) ? ~0u : ((1u << nput) - 1u);
+        empty &= ~filled;
+      }
+      else
+#endif
       while (todo_l > 0 && j < kFoodLanes) {
         const unsigned long long okm = __ballot(ok) & (~0ull << j);
         const int first_ok = okm ? (__ffsll((long long)okm) - 1) : kFoodLanes;
