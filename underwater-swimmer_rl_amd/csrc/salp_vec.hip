@@ -39,6 +39,9 @@ constexpr int kWave = 64;
 #ifndef SALP_MULTI_WAVES_OTHER
 #define SALP_MULTI_WAVES_OTHER 3
 #endif
+#ifndef SALP_F16_HALF
+#define SALP_F16_HALF 1     // 16-slot literal-constant kernels: half-height tile, no fp32 register copies, three wavefronts per SIMD
+#endif
 #ifndef SALP_SMALL_WAVES
 #define SALP_SMALL_WAVES 4     // 4- and 8-slot kernels with the literal constants: 128 VGPRs (their LDS allows four workgroups per CU); without the
 #endif                         // bound the non-FULL signatures landed on 129 = three per SIMD, 22 % slower (ab_notes.md session 14); STD = false: 3
@@ -95,7 +98,7 @@ struct ColdBlock {
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
 template <int FMAX, int KMAX, bool FORCED, bool STD, int SIG, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 && STD ? SALP_SMALL_WAVES : (FMAX <= 12 ? (KMAX == 3 ? (STD ? SALP_MULTI_WAVES : SALP_MULTI_WAVES_OTHER) : 2) : (KMAX == 3 ? 2 : 1))))) void salp_rollout_kernel(DevParams P_arg, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 && STD ? SALP_SMALL_WAVES : (FMAX <= 12 ? (KMAX == 3 ? (STD ? SALP_MULTI_WAVES : SALP_MULTI_WAVES_OTHER) : 2) : (KMAX == 3 ? ((SALP_F16_HALF && STD && !RAGGED) ? 3 : 2) : 1))))) void salp_rollout_kernel(DevParams P_arg, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
   // STD = false: where the hot path's constants come from (open_consts, salp_device.h) — the device copy, function by
   // function, for the 4- and 8-slot kernels; the by-value launch parameters for the others
   constexpr bool MEMC = !STD && KMAX == 3 && (FMAX == 4 || FMAX == 8);
@@ -128,9 +131,14 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
   // 12 slots, K = 3: 6144 + 6144 B per wavefront, 49 KB per workgroup -> 3 workgroups per CU.  The tile's bytes, idle in
   // the middle of a step, are lent to the rare paths as scratch: the exact order's distances (8 B per slot and lane,
   // <= the tile for every instantiation) and the placement's accepted points.
-  constexpr int TILE_FLOATS = kWave * PITCH;
+  // HALF: a tile of 32 rows, written and flushed twice per step (lanes 0-31, then 32-63): 3072 instead of 6144 B per wavefront.
+  // The 16-slot kernel's mirror is 8192 B per wavefront: 57344 B per workgroup allowed two workgroups per CU, 45056 B allow three
+  // (and without the fp32 register copies it holds 159 VGPRs <= 168).
+  constexpr bool HALF = SALP_F16_HALF && !RAGGED && REGF && KMAX == 3 && FMAX == 16 && STD;
+  constexpr int TILE_ROWS = HALF ? kWave / 2 : kWave;
+  constexpr int TILE_FLOATS = TILE_ROWS * PITCH;
   constexpr int WAVE_FLOATS = TILE_FLOATS + (REGF ? kWave * 2 * FMAX : 0);
-  static_assert(!REGF || 4 * FMAX <= kWave * PITCH, "the placement's FMAX accepted points (16 B each) must fit in the tile");
+  static_assert(!REGF || (4 * FMAX <= TILE_ROWS * PITCH && 96 <= TILE_ROWS * PITCH), "the placement's FMAX accepted points (16 B each) must fit in the tile");
   __shared__ __attribute__((aligned(16))) float lds[(kBlock / kWave) * WAVE_FLOATS];
 
   const int tid = threadIdx.x;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
   const int OD = 4 * Q;
   const int AD = FORCED ? 1 : 2;
   float* tile = lds + wave * WAVE_FLOATS;
-  float4* myrow4 = reinterpret_cast<float4*>(tile + lane * PITCH);
+  float4* myrow4 = reinterpret_cast<float4*>(tile + (HALF ? (lane & (TILE_ROWS - 1)) : lane) * PITCH);
   // SWZ: column q of this lane's row sits at float4 (q ^ s), s = bit 2 of the row = q + s for even q, q - s for odd q
   const int swz = SWZ ? ((lane >> 2) & 1) : 0;
   float4* myrow_even = myrow4 + swz;
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
   EnvT e;
   const FoodLds food{food_lds + (LDSF ? (wave * FMAX * kWave + lane) : 0)};
   const MirrorLds mir{reinterpret_cast<float2*>(tile + TILE_FLOATS) + lane};   // REGF only
-  FoodF32<REGF ? FMAX : 1, food_in_registers(FMAX, KMAX, STD, SIG == 1)> ff;   // REGF: fp32 roundings of the food positions (salp_food_reg.h)
+  FoodF32<REGF ? FMAX : 1, food_in_registers(FMAX, KMAX, STD, SIG == 1) && !HALF> ff;   // REGF: fp32 roundings of the food positions (salp_food_reg.h)
   FoodScan<KMAX> fq;          // MULTI: nearest-K selection of the current food set around the current pose
   int nlive = 0;              // MULTI: live foods of this env, recounted whenever the food set changes
   int order_cache = -1;       // REGF: remembered exact order of a resting swimmer's foods (step_env_reg)
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        else if constexpr (REGF) place_food_coop_reg<FMAX, STD, food_in_registers(FMAX, KMAX, STD, SIG == 1)>(e, ff, mir, lane, C, genv, todo, limit, reinterpret_cast<double2*>(tile));
+        else if constexpr (REGF) place_food_coop_reg<FMAX, STD, food_in_registers(FMAX, KMAX, STD, SIG == 1) && !HALF>(e, ff, mir, lane, C, genv, todo, limit, reinterpret_cast<double2*>(tile));
         else place_food<FMAX, STD>(e, C, genv, todo, limit);
         todo = 0;
       }
@@ -421,13 +429,36 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
       else observe<FMAX, KMAX, STD>(e, P, rmax, have_rel, o.rel, ob);
       SALP_STAMP(8);
       // (per-lane 96-B rows stored straight from registers, without the LDS transpose: 2.1x slower, r01 ab_notes)
+      v4f* gout = reinterpret_cast<v4f*>(io.obs + (rowbase + env0) * OD) + lane;
+      if constexpr (HALF) {
+        // float4 f = j*64 + lane (j = 0..2) of a half lives at tile row f / 6, column f % 6 (flush_src[0..2]) and goes to global
+        // float4 (3 h + j) * 64 + lane of the wavefront's 64-row block: the same 1-KB stores as the full plan, three per half
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if ((lane >> 5) == h) {
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q)
+              ((q & 1) ? myrow_odd : myrow_even)[q] = make_float4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          v4f tv[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) tv[j] = *flush_src[j];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) __builtin_nontemporal_store(tv[j], &gout[(3 * h + j) * kWave]);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the reads of this half before the writes of the next
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      } else {
 #pragma unroll
       for (int q = 0; q < QMAX; ++q)   // 16-B LDS stores, conflict-free (see the tile layout above)
         if (q < Q) ((q & 1) ? myrow_odd : myrow_even)[q] = make_float4(ob[4 * q], ob[4 * q + 1], ob[4 * q + 2], ob[4 * q + 3]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      v4f* gout = reinterpret_cast<v4f*>(io.obs + (rowbase + env0) * OD) + lane;
       {
         v4f tv[QMAX];
 #pragma unroll
@@ -458,6 +489,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 &&
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
     }
     // One-food kernel (write-bound): drain this step's stores before the next step.  Measured
     // (profiles/r01/ab_notes.md): letting stores run ahead (vmcnt(9)) is 2-6 % SLOWER than draining —
