@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
 import test_gpu_parity as T
 import oracle_lib as ol
 bad = 0
-for case in range(100, 220):
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (100, 220)
+for case in range(lo, hi):
     rng = np.random.default_rng(5000 + case)
     cfg = T._random_cfg(rng)
     n, H, seed = 321, 200, int(rng.integers(0, 2 ** 31))

@@ -288,6 +288,33 @@ __device__ __forceinline__ void resolve_f32(const MirrorLds& m, int K, float xf,
   }
 }
 
+// The fp32 offsets carry the roundings of both positions (up to ~6e-5 px in an 800-wide tank): a bearing error of 6e-5 / d rad.
+// A live food is normally at least a capture radius away (d >= ~48 px: 1.3e-6 rad), but a fallback placement (snake:120-131,
+// :270-276: the unconditional draw after the rejections are used up, crowded tanks only) can put one next to the swimmer, and
+// with two foods inside the capture radius the farther slot survives a step: seen at d = 0.7 px, where the shaped reward
+// 5 cos(bearing) was off by 8e-5 (tests/soak_main_kernels.py case 92).  So for observed foods nearer than 0.05 max(W, H)
+// (40 px: inside every default capture radius) the offsets are taken from the exact positions; wave-uniform and rare.
+template <int FMAX, int KMAX>
+__device__ __forceinline__ void refine_near(const Env<FMAX>& e, int K, float tol_c0, FoodScan<KMAX>& q) {
+  const float near2 = tol_c0 * 17857.f;            // tol_c0 = 1.4e-7 L^2  ->  (0.05 L)^2
+  // entry 0, the nearest: the one the reward reads; a second food that close as well has not been seen
+  const bool nr = (K > 0) && (q.idx[0] >= 0) && (q.bd[0] * q.bd[0] < near2);
+  if (__any(nr)) {
+    double dx = 0.0, dy = 0.0;
+#pragma unroll
+    for (int k = 0; k < FMAX; ++k) {
+      const bool h = nr && (q.idx[0] == k);
+      double ex = e.x, ey = e.y;
+      asm volatile("" : "+v"(ex), "+v"(ey));      // one slot at a time, inside this branch (see exact_order_reg)
+      dx = h ? (e.fx[k] - ex) : dx;
+      dy = h ? (e.fy[k] - ey) : dy;
+    }
+    q.bx[0] = nr ? (float)dx : q.bx[0];
+    q.by[0] = nr ? (float)dy : q.by[0];
+    q.bd[0] = nr ? (float)__builtin_sqrt(dx * dx + dy * dy) : q.bd[0];
+  }
+}
+
 // Selection of the current food set around the current pose: pass, exact order where needed, geometry.
 template <int FMAX, int KMAX, bool ALLLIVE, bool COUNT, bool INREG>
 __device__ __forceinline__ void select_foods_reg(const Env<FMAX>& e, const FoodF32<FMAX, INREG>& ff, const MirrorLds& m, int K,
@@ -296,6 +323,7 @@ __device__ __forceinline__ void select_foods_reg(const Env<FMAX>& e, const FoodF
   scan_foods_f32<FMAX, KMAX, ALLLIVE, COUNT>(ff, m, K, xf, yf, tol_c0, q, cnt);
   if (__any(q.tie)) exact_order_reg<FMAX, KMAX>(e, K, q);
   resolve_f32<KMAX, ALLLIVE>(m, K, xf, yf, q);
+  refine_near<FMAX, KMAX>(e, K, tol_c0, q);
 }
 
 // snake:204-217 _check_food_collection on the fp64 positions, in the reference's arithmetic: the first live food
@@ -411,6 +439,7 @@ __device__ __forceinline__ StepOut step_env_reg(Env<FMAX>& e, FoodF32<FMAX, INRE
   }
   if (all_live) resolve_f32<KMAX, true>(m, Ksel, xf, yf, q);
   else resolve_f32<KMAX, false>(m, Ksel, xf, yf, q);
+  refine_near<FMAX, KMAX>(e, Ksel, tol_c0, q);
   {
     const double mg = CV(margin);
     o.collision = (e.x - r <= mg) || (e.x + r >= CV(wall_hi_x)) || (e.y - r <= mg) || (e.y + r >= CV(wall_hi_y));

@@ -43,8 +43,8 @@ constexpr int kWave = 64;
 #define SALP_F16_HALF 1     // 16-slot literal-constant kernels: half-height tile, no fp32 register copies, three wavefronts per SIMD
 #endif
 #ifndef SALP_SMALL_WAVES
-#define SALP_SMALL_WAVES 4     // 4- and 8-slot kernels with the literal constants: 128 VGPRs (their LDS allows four workgroups per CU); without the
-#endif                         // bound the non-FULL signatures landed on 129 = three per SIMD, 22 % slower (ab_notes.md session 14); STD = false: 3
+#define SALP_SMALL_WAVES 4     // 4- and 8-slot kernels (literal constants, or constants read from memory): 128 VGPRs (their LDS allows four workgroups per CU); without the
+#endif                         // bound signatures landed on 129 = three per SIMD, up to 22 % slower (ab_notes.md sessions 14, 20)
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -98,7 +98,7 @@ struct ColdBlock {
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
 template <int FMAX, int KMAX, bool FORCED, bool STD, int SIG, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 && STD ? SALP_SMALL_WAVES : (FMAX <= 12 ? (KMAX == 3 ? (STD ? SALP_MULTI_WAVES : SALP_MULTI_WAVES_OTHER) : 2) : (KMAX == 3 ? ((SALP_F16_HALF && STD && !RAGGED) ? 3 : 2) : 1))))) void salp_rollout_kernel(DevParams P_arg, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 ? SALP_SMALL_WAVES : (FMAX <= 12 ? (KMAX == 3 ? (STD ? SALP_MULTI_WAVES : SALP_MULTI_WAVES_OTHER) : 2) : (KMAX == 3 ? ((SALP_F16_HALF && STD && !RAGGED) ? 3 : 2) : 1))))) void salp_rollout_kernel(DevParams P_arg, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
   // STD = false: where the hot path's constants come from (open_consts, salp_device.h) — the device copy, function by
   // function, for the 4- and 8-slot kernels; the by-value launch parameters for the others
   constexpr bool MEMC = !STD && KMAX == 3 && (FMAX == 4 || FMAX == 8);
