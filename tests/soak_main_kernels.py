@@ -17,7 +17,8 @@ import underwater_swimmer_rl_amd as pkg   # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 bad = 0
-for case in range(cases):
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0       # soak_main_kernels.py <end> [<first>]
+for case in range(first, cases):
     rng = np.random.default_rng(9000 + case)
     F = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 12, 13, 16]))
     kw = dict(num_food_items=F, forced_breathing=bool(rng.random() < 0.7), random_food_count=bool(rng.random() < 0.3),
