@@ -87,7 +87,9 @@ struct DevParams {
                             // reads them where it draws, so salp_vec_reseed() changes them without changing any launch
                             // parameter — a hipGraph captured before a reseed replays with the new key
   dev_params_c* self;       // this block in DEVICE memory (the handle's ColdBlock): where the STD = false kernels read their
-                            // constants, function by function (open_consts below)
+                            // constants, function by function (open_consts below); always valid
+  int use_mem;              // 1: read the constants through `self` (set by the kernel on its own copy, a compile-time constant
+                            // there; 0 from the host)
   uint64_t env_base;        // global index of local env 0
   int64_t n;                // envs in this handle
   int64_t pitch;            // row pitch (elements) of the SoA state blocks
@@ -119,12 +121,14 @@ struct StdConsts {
 // loads (s_load_dwordx2..x16, scalar cache) stay in that function, and the registers are free again after it.
 // Measured (ab_pc_f*.json): 4- and 8-slot kernels -5 ... -15 % (125 VGPRs, four wavefronts per SIMD again); one-food +1.4 %,
 // 12- and 16-slot kernels +13 % (two / three wavefronts per SIMD do not hide the scalar-load waits) — so a kernel chooses:
-// it hands its functions a parameter block whose `self` is a compile-time NULL to keep the by-value constants.
+// it hands its functions a parameter block whose `use_mem` is a compile-time 0 to keep the by-value constants.
 template <bool STD>
 __device__ __forceinline__ dev_params_c* open_consts(const DevParams& P) {
   if constexpr (STD) return nullptr;
   else {
-    if (__builtin_constant_p(P.self == nullptr) && P.self == nullptr) return nullptr;   // resolved after inlining
+    // `use_mem` is a literal in the kernel's own copy of the parameters and every caller is __forceinline__: the test folds.
+    // (Should it ever not fold, it is a wave-uniform run-time test and both forms stay correct: `self` is always valid.)
+    if (!P.use_mem) return nullptr;
     // (the rare paths hand in the memory copy itself: its `self` word may arrive through a vector load)
     const uint64_t a = (uint64_t)(uintptr_t)P.self;
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);

@@ -102,9 +102,9 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 ? 
   // STD = false: where the hot path's constants come from (open_consts, salp_device.h) — the device copy, function by
   // function, for the 4- and 8-slot kernels; the by-value launch parameters for the others
   constexpr bool MEMC = !STD && KMAX == 3 && (FMAX == 4 || FMAX == 8);
-  DevParams P_byval = P_arg;
-  P_byval.self = nullptr;
-  const DevParams& P = (STD || MEMC) ? P_arg : P_byval;
+  DevParams P_pol = P_arg;
+  P_pol.use_mem = MEMC ? 1 : 0;
+  const DevParams& P = STD ? P_arg : P_pol;
   constexpr bool FULL = SIG != 0;         // obs, reward, terminated, truncated all present: their stores are unconditional
   constexpr bool EXTRAS = SIG != 1;       // final_obs / info may be present (tested per use; SIG 0: every output is tested)
   constexpr int QMAX = 3 + KMAX;          // float4 per observation row
