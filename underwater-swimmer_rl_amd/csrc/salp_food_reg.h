@@ -40,11 +40,8 @@ struct MirrorLds {
 // holds at three / two wavefronts per SIMD anyway (49 / 57 KB per workgroup: room for 168 / 256 VGPRs; the 12-slot kernel
 // gains 2.7 % from the copies).  The 4- and 8-slot kernels read the mirror instead: they fit four wavefronts per SIMD by LDS
 // (32 / 40 KB), and only without the copies by registers (<= 128 VGPRs; profiles/r03/ab_notes.md sessions 9 and 12).
-#ifndef SALP_INREG_ALWAYS
-#define SALP_INREG_ALWAYS 0
-#endif
 constexpr bool food_in_registers(int fmax, int kmax, bool std_consts, bool full) {
-  return kmax == 3 && (fmax > 12 || (fmax == 12 && (SALP_INREG_ALWAYS || (std_consts && full))));
+  return kmax == 3 && (fmax > 12 || (fmax == 12 && std_consts && full));
 }
 
 // What the per-step pass reads (static slot index).  INREG (the K = 3 kernels): the mirror's values also in registers —
@@ -512,7 +509,6 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, FoodF32<FMAX, 
       }
       int j = 0;                                   // first candidate of this batch not yet judged
       uint32_t filled = 0u;                        // slots of env L that received a point in this batch
-#ifndef SALP_EXP_NO_FAST_RESET
       // First batch of an autoreset (no food yet, the empty slots are 0 .. nE-1): the same sequential rule on bit masks.  A
       // candidate's standing is `blocked` — the union of the accepted candidates' conflict rows (one ballot each) — instead of
       // a per-lane flag re-tested every round, and the accepted points are handed over together: the k-th accepted lane
@@ -543,7 +539,6 @@ __device__ __forceinline__ void place_food_coop_reg(Env<FMAX>& e, FoodF32<FMAX, 
         empty &= ~filled;
       }
       else
-#endif
       while (todo_l > 0 && j < kFoodLanes) {
         const unsigned long long okm = __ballot(ok) & (~0ull << j);
         const int first_ok = okm ? (__ffsll((long long)okm) - 1) : kFoodLanes;

@@ -33,18 +33,14 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kBlock = 256;
 constexpr int kWave = 64;
-#ifndef SALP_MULTI_WAVES
-#define SALP_MULTI_WAVES 3     // 12-slot kernels: <= 168 VGPRs, 3 wavefronts per SIMD (four: 49 KB of LDS forbid it, and a timing build at 128 VGPRs / 36 KB was 13 % slower, r03 session 17)
-#endif
-#ifndef SALP_MULTI_WAVES_OTHER
-#define SALP_MULTI_WAVES_OTHER 3
-#endif
-#ifndef SALP_F16_HALF
-#define SALP_F16_HALF 1     // 16-slot literal-constant kernels: half-height tile, no fp32 register copies, three wavefronts per SIMD
-#endif
-#ifndef SALP_SMALL_WAVES
-#define SALP_SMALL_WAVES 4     // 4- and 8-slot kernels (literal constants, or constants read from memory): 128 VGPRs (their LDS allows four workgroups per CU); without the
-#endif                         // bound signatures landed on 129 = three per SIMD, up to 22 % slower (ab_notes.md sessions 14, 20)
+// Wavefronts per SIMD the launch bounds ask for (workgroups of 256 threads per CU), by food-slot count:
+//   one food 4;  4 / 8 slots 4 — 128 VGPRs, their LDS (32 / 40 KB) allows four workgroups per CU; without the bound several
+//   signatures landed on 129 = three per SIMD, up to 22 % slower (profiles/r03/ab_notes.md sessions 14, 20);  12 slots 3 —
+//   <= 168 VGPRs, 49 KB of LDS (four: a timing build at 128 VGPRs / 36 KB was 13 % slower, session 17);  16 slots 3 for the
+//   literal-constant unpredicated kernels (half-height tile, session 19), else 2;  generic K: 2 (12 slots) / 1 (16 slots).
+constexpr int waves_per_simd(int fmax, int kmax, bool std_consts, bool ragged) {
+  return fmax <= 1 ? 4 : (kmax != 3 ? (fmax <= 12 ? 2 : 1) : (fmax <= 8 ? 4 : (fmax <= 12 ? 3 : ((std_consts && !ragged) ? 3 : 2))));
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -98,7 +94,7 @@ struct ColdBlock {
 // all — the per-step 256-B action read costs the write stream ~10 % (HBM read/write turnarounds,
 // profiles/r01/ab_notes.md) — and, if act_out is given, the actions are written out instead.
 template <int FMAX, int KMAX, bool FORCED, bool STD, int SIG, bool RAGGED, bool GEN>
-__global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 ? SALP_SMALL_WAVES : (FMAX <= 12 ? (KMAX == 3 ? (STD ? SALP_MULTI_WAVES : SALP_MULTI_WAVES_OTHER) : 2) : (KMAX == 3 ? ((SALP_F16_HALF && STD && !RAGGED) ? 3 : 2) : 1))))) void salp_rollout_kernel(DevParams P_arg, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
+__global__ __launch_bounds__(kBlock, waves_per_simd(FMAX, KMAX, STD, RAGGED)) void salp_rollout_kernel(DevParams P_arg, DevState S, IOPtrs io, int H, int64_t env_begin, int64_t env_end, const ColdBlock* __restrict__ cold) {
   // STD = false: where the hot path's constants come from (open_consts, salp_device.h) — the device copy, function by
   // function, for the 4- and 8-slot kernels; the by-value launch parameters for the others
   constexpr bool MEMC = !STD && KMAX == 3 && (FMAX == 4 || FMAX == 8);
@@ -134,7 +130,7 @@ __global__ __launch_bounds__(kBlock, (FMAX <= 1 ? 4 : (FMAX <= 8 && KMAX == 3 ? 
   // HALF: a tile of 32 rows, written and flushed twice per step (lanes 0-31, then 32-63): 3072 instead of 6144 B per wavefront.
   // The 16-slot kernel's mirror is 8192 B per wavefront: 57344 B per workgroup allowed two workgroups per CU, 45056 B allow three
   // (and without the fp32 register copies it holds 159 VGPRs <= 168).
-  constexpr bool HALF = SALP_F16_HALF && !RAGGED && REGF && KMAX == 3 && FMAX == 16 && STD;
+  constexpr bool HALF = !RAGGED && REGF && KMAX == 3 && FMAX == 16 && STD;
   constexpr int TILE_ROWS = HALF ? kWave / 2 : kWave;
   constexpr int TILE_FLOATS = TILE_ROWS * PITCH;
   constexpr int WAVE_FLOATS = TILE_FLOATS + (REGF ? kWave * 2 * FMAX : 0);
